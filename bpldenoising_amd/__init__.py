@@ -1,0 +1,14 @@
+"""bpldenoising_amd -- MI355X-native inner TV-denoising solver behind BPLDenoising's
+evaluate/solve surface (tv_op_learning_function / denoise / TVDenoise).
+
+Product path: libbpltv.so (hand-written HIP for gfx950, C ABI in include/bpltv.h).  This package
+is the thin host mirror of the reference's operator interface; it has no CPU fallback.
+"""
+from .learning_function import (FwdGradientOp, L2CostFunction, TVDenoise, TVSolver, denoise,
+                                tv_op_learning_function)
+from .sharding import ShardedLearningFunction, shard_range
+from .datasets import testdataset, load_filelist_dataset
+
+__all__ = ["FwdGradientOp", "L2CostFunction", "TVDenoise", "TVSolver", "denoise",
+           "tv_op_learning_function", "ShardedLearningFunction", "shard_range", "testdataset",
+           "load_filelist_dataset"]

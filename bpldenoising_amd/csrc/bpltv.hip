@@ -1,0 +1,767 @@
+// bpltv.hip -- libbpltv: handle, launch logic and the C ABI declared in include/bpltv.h.
+//
+// Drop-in boundary: /root/reference/src/TVLearningFunctionVec.jl:14-27 (tv_op_learning_function),
+// :45-70 (denoise), /root/reference/src/BPLDenoising.jl:41-82 (TVDenoise).  The product path is
+// GPU only: there is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/bpltv.h"
+#include "adjoint_kernels.hpp"
+#include "pdhg_kernels.hpp"
+
+using namespace bpltv;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// PDHG kernel variants: (PI, PJ) pixels per thread, (TI, TJ) threads; region = PI*TI x PJ*TJ.
+// ------------------------------------------------------------------------------------------
+struct Variant {
+    int RI, RJ, threads;
+    void (*launch)(const PdhgArgs&, int grid, hipStream_t);
+    const char* name;
+};
+
+template <int PI, int PJ, int TI, int TJ>
+void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    constexpr size_t lds = sizeof(double) * 3 * (PI * TI) * (PJ * TJ);
+    hipLaunchKernelGGL((pdhg_tile_kernel<PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
+}
+
+#define VAR(PI, PJ, TI, TJ) \
+    { PI * TI, PJ * TJ, TI * TJ, &launch_variant<PI, PJ, TI, TJ>, #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
+const Variant kVariants[] = {
+    VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
+    VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread   (large images, deep blocking)
+    VAR(1, 1, 16, 16),  // 3: 16x16 region
+    VAR(2, 2, 16, 16),  // 4: 32x32 region, 256 threads
+    VAR(2, 1, 32, 32),  // 5: 64x32 region
+    VAR(4, 4, 16, 16),  // 6: 64x64 region, 256 threads, 16 px/thread
+    VAR(1, 1, 64, 16),  // 7: 64x16 region (512 B rows)
+    VAR(2, 1, 64, 16),  // 8: 128x16 region
+    VAR(2, 2, 64, 16),  // 9: 128x32 region
+    VAR(1, 2, 32, 32),  // 10: 32x64 region
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+struct GraphKey {
+    int maxiter, T, variant, am, an;
+    double rho, tau0, sigma0;
+    int accel;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(maxiter, T, variant, am, an, rho, tau0, sigma0, accel) <
+               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.rho, o.tau0, o.sigma0, o.accel);
+    }
+};
+
+struct TabKey {
+    int maxiter, accel;
+    double tau0, sigma0;
+    bool operator<(const TabKey& o) const {
+        return std::tie(maxiter, accel, tau0, sigma0) < std::tie(o.maxiter, o.accel, o.tau0, o.sigma0);
+    }
+};
+
+}  // namespace
+
+struct bpltv_handle {
+    int M = 0, N = 0, O = 0, device = 0;
+    size_t npx = 0, tot = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool has_data = false;
+    // dataset + state
+    double *d_ubar = nullptr, *d_f = nullptr;
+    double* d_state[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int result_buf = 0;  // which state set holds the last result
+    bool has_result = false;
+    double* d_alpha = nullptr;
+    size_t alpha_cap = 0;
+    int last_am = 1, last_an = 1;
+    double* d_partial = nullptr;  // [1 + am*an]
+    size_t partial_cap = 0;
+    double* d_red = nullptr;      // reduction scratch
+    size_t red_cap = 0;
+    double* d_perimg = nullptr;   // [O] cost per image / gap per image
+    double* d_scalar = nullptr;   // [4]
+    std::map<TabKey, double*> tabs;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    // adjoint workspace (lazy)
+    bool adj_ready = false;
+    double* d_coef = nullptr;   // 8 planes
+    double* d_band4 = nullptr;  // 4 planes
+    double* d_L = nullptr;
+    double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
+    double* d_resn = nullptr;
+    int* d_fail = nullptr;
+    double *d_u2 = nullptr, *d_ubar2 = nullptr;  // staging for bpltv_gradient
+    bpltv_stats_t st;
+    std::string err;
+};
+
+namespace {
+
+int set_err(bpltv_t* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_err(h, BPLTV_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                  \
+    } while (0)
+
+int ensure(bpltv_t* h, double** p, size_t* cap, size_t need) {
+    if (*cap >= need) return BPLTV_OK;
+    if (*p) HIPCHK(h, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(h, hipMalloc((void**)p, need * sizeof(double)));
+    *cap = need;
+    return BPLTV_OK;
+}
+
+void fill_table(const TabKey& k, std::vector<double>& tab) {
+    // oracle/bpltv_oracle.c: bplo_step_table (same operations, same order)
+    const double L = std::sqrt(8.0);
+    double tau = k.tau0 / L, sigma = k.sigma0 / L;
+    const double gamma = 1.0;
+    tab.assign((size_t)TAB_STRIDE * (k.maxiter > 0 ? k.maxiter : 1), 0.0);
+    for (int it = 0; it < k.maxiter; ++it) {
+        const double omega = k.accel ? 1.0 / std::sqrt(1.0 + 2.0 * gamma * tau) : 1.0;
+        double* r = &tab[(size_t)TAB_STRIDE * it];
+        r[0] = tau;
+        r[1] = sigma;
+        r[2] = omega;
+        r[3] = 1.0 / (1.0 + tau);
+        r[4] = 1.0 + omega;
+        if (k.accel) {
+            tau = tau * omega;
+            sigma = sigma / omega;
+        }
+    }
+}
+
+int get_table(bpltv_t* h, const bpltv_params& p, double** out) {
+    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0};
+    auto it = h->tabs.find(k);
+    if (it != h->tabs.end()) {
+        *out = it->second;
+        return BPLTV_OK;
+    }
+    std::vector<double> tab;
+    fill_table(k, tab);
+    double* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, tab.size() * sizeof(double)));
+    HIPCHK(h, hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->tabs[k] = d;
+    *out = d;
+    return BPLTV_OK;
+}
+
+void drop_graphs(bpltv_t* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+int upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
+    if (!alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
+    if (am > h->M || an > h->N)
+        return set_err(h, BPLTV_E_ARG, "alpha shape %dx%d exceeds image %dx%d", am, an, h->M, h->N);
+    const size_t need = (size_t)am * an;
+    if (h->alpha_cap < need) {
+        drop_graphs(h);  // captured kernels hold the old pointer
+        int rc = ensure(h, &h->d_alpha, &h->alpha_cap, need);
+        if (rc) return rc;
+    }
+    if (h->partial_cap < need + 1) {
+        int rc = ensure(h, &h->d_partial, &h->partial_cap, need + 1);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_alpha, alpha, need * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->last_am = am;
+    h->last_an = an;
+    return BPLTV_OK;
+}
+
+struct Plan {
+    int variant, T, nTi, nTj, grid;
+};
+
+int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
+    int v = p.reserved[0] - 1;  // explicit variant (1-based), 0 = auto
+    const int M = h->M, N = h->N;
+    if (v < 0) v = (M > 256 || N > 256) ? 1 : 0;
+    if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
+    const Variant& V = kVariants[v];
+    int T = p.tile_iters;
+    if (T <= 0) T = (V.RI >= 64 && V.RJ >= 64) ? 8 : 4;
+    // the halo must leave a core when the image is larger than the region
+    auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
+    int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
+    if (T > cap) T = cap;
+    if (T < 1) return set_err(h, BPLTV_E_ARG, "tile_iters must be >= 1");
+    pl->variant = v;
+    pl->T = T;
+    pl->nTi = tile_count(M, V.RI, T);
+    pl->nTj = tile_count(N, V.RJ, T);
+    if (pl->nTi < 1 || pl->nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
+    pl->grid = pl->nTi * pl->nTj * h->O;
+    return BPLTV_OK;
+}
+
+// Enqueue PDHG iterations [it0, it1) on the stream.  *buf: state set holding the current iterate
+// (ignored when it0 == 0), updated to the set holding the result.
+int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab, int it0, int it1,
+                 int* buf, int* launches) {
+    const Variant& V = kVariants[pl.variant];
+    PdhgArgs a;
+    a.f = h->d_f;
+    a.alpha = h->d_alpha;
+    a.tab = d_tab;
+    a.rho = p.rho;
+    a.am = h->last_am;
+    a.an = h->last_an;
+    a.M = h->M; a.N = h->N; a.O = h->O;
+    a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
+    int cur = *buf;
+    for (int it = it0; it < it1; it += pl.T) {
+        const int nit = std::min(pl.T, it1 - it);
+        const int nxt = (it == 0) ? 0 : 1 - cur;
+        a.first = (it == 0) ? 1 : 0;
+        a.xin = h->d_state[cur][0]; a.y1in = h->d_state[cur][1]; a.y2in = h->d_state[cur][2];
+        a.xout = h->d_state[nxt][0]; a.y1out = h->d_state[nxt][1]; a.y2out = h->d_state[nxt][2];
+        a.it0 = it;
+        a.nit = nit;
+        V.launch(a, pl.grid, h->stream);
+        cur = nxt;
+        ++*launches;
+    }
+    HIPCHK(h, hipGetLastError());
+    *buf = cur;
+    return BPLTV_OK;
+}
+
+int compute_gap(bpltv_t* h, double* gap_host /*O or null*/, double* gap_max_host) {
+    const int nblk = 8;
+    int rc = ensure(h, &h->d_red, &h->red_cap, (size_t)h->O * nblk * 4);
+    if (rc) return rc;
+    const int b = h->result_buf;
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(nblk, h->O), dim3(256), 0, h->stream, h->d_state[b][0],
+                       h->d_state[b][1], h->d_state[b][2], h->d_f, h->d_alpha, h->last_am, h->last_an, h->M,
+                       h->N, h->d_red);
+    hipLaunchKernelGGL(gap_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, nblk, h->O, h->d_perimg,
+                       h->d_scalar);
+    HIPCHK(h, hipGetLastError());
+    if (gap_host)
+        HIPCHK(h, hipMemcpyAsync(gap_host, h->d_perimg, sizeof(double) * h->O, hipMemcpyDeviceToHost, h->stream));
+    if (gap_max_host)
+        HIPCHK(h, hipMemcpyAsync(gap_max_host, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BPLTV_OK;
+}
+
+int run_pdhg(bpltv_t* h, const bpltv_params& p) {
+    if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
+    if (p.maxiter < 0) return set_err(h, BPLTV_E_ARG, "maxiter < 0");
+    Plan pl;
+    int rc = make_plan(h, p, &pl);
+    if (rc) return rc;
+    double* d_tab = nullptr;
+    rc = get_table(h, p, &d_tab);
+    if (rc) return rc;
+    h->st.tile_iters = pl.T;
+    h->st.tiles = pl.grid;
+    h->st.launches = 0;
+    h->st.iterations = 0;
+    h->st.graph_used = 0;
+    h->st.last_gap = -1.0;
+    int buf = 0, launches = 0;
+    if (p.maxiter == 0) {  // u = f
+        for (int c = 0; c < 3; ++c) {
+            if (c == 0)
+                HIPCHK(h, hipMemcpyAsync(h->d_state[0][0], h->d_f, h->tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            else
+                HIPCHK(h, hipMemsetAsync(h->d_state[0][c], 0, h->tot * sizeof(double), h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->result_buf = 0;
+        h->has_result = true;
+        h->st.pdhg_ms = 0.0;
+        return BPLTV_OK;
+    }
+    const bool chunked = p.check_every > 0;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (!chunked) {
+        bool done = false;
+        if (p.use_graph) {
+            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0};
+            auto it = h->graphs.find(key);
+            hipGraphExec_t exec = nullptr;
+            const int nl = (p.maxiter + pl.T - 1) / pl.T;
+            if (it == h->graphs.end()) {
+                hipGraph_t g = nullptr;
+                hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    int b2 = 0, l2 = 0;
+                    int rc2 = enqueue_pdhg(h, p, pl, d_tab, 0, p.maxiter, &b2, &l2);
+                    e = hipStreamEndCapture(h->stream, &g);
+                    if (rc2 == BPLTV_OK && e == hipSuccess && g) {
+                        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+                        if (e == hipSuccess) h->graphs[key] = exec; else exec = nullptr;
+                    }
+                    if (g) (void)hipGraphDestroy(g);
+                }
+                (void)hipGetLastError();
+            } else {
+                exec = it->second;
+            }
+            if (exec) {
+                // the capture left the stream's event record outside the graph; record again
+                HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+                HIPCHK(h, hipGraphLaunch(exec, h->stream));
+                buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
+                launches = nl;
+                h->st.graph_used = 1;
+                done = true;
+            }
+        }
+        if (!done) {
+            rc = enqueue_pdhg(h, p, pl, d_tab, 0, p.maxiter, &buf, &launches);
+            if (rc) return rc;
+        }
+        h->st.iterations = p.maxiter;
+    } else {
+        int it = 0;
+        while (it < p.maxiter) {
+            const int it1 = std::min(p.maxiter, it + p.check_every);
+            rc = enqueue_pdhg(h, p, pl, d_tab, it, it1, &buf, &launches);
+            if (rc) return rc;
+            it = it1;
+            h->result_buf = buf;
+            double gmax = 0.0;
+            rc = compute_gap(h, nullptr, &gmax);
+            if (rc) return rc;
+            h->st.last_gap = gmax;
+            if (p.gap_tol > 0.0 && gmax <= p.gap_tol) break;
+        }
+        h->st.iterations = it;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->st.pdhg_ms = ms;
+    h->st.launches = launches;
+    h->result_buf = buf;
+    h->has_result = true;
+    const bool amap = (h->last_am == h->M && h->last_an == h->N) && !(h->M == 1 && h->N == 1);
+    h->st.bytes_per_px_iter = amap ? 64.0 : 56.0;
+    h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->tot * h->st.iterations;
+    return BPLTV_OK;
+}
+
+int compute_cost(bpltv_t* h, const double* d_u, const double* d_ubar, double* d_out /*device scalar*/) {
+    const int nblk = 16;
+    int rc = ensure(h, &h->d_red, &h->red_cap, (size_t)h->O * nblk * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cost_partial_kernel, dim3(nblk, h->O), dim3(256), 0, h->stream, d_u, d_ubar, (int)h->npx,
+                       h->d_red);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, nblk, h->O, 0.5, h->d_perimg,
+                       d_out);
+    HIPCHK(h, hipGetLastError());
+    return BPLTV_OK;
+}
+
+int adj_alloc(bpltv_t* h) {
+    if (h->adj_ready) return BPLTV_OK;
+    const size_t tot = h->tot;
+    const size_t W = (size_t)h->M + 1;
+    if ((W * W + W) * sizeof(double) > 160 * 1024)
+        return set_err(h, BPLTV_E_UNSUPPORTED,
+                       "adjoint gradient: M = %d needs a %zu-byte LDS window (limit 163840); M <= 141 supported",
+                       h->M, (W * W + W) * sizeof(double));
+    HIPCHK(h, hipMalloc((void**)&h->d_coef, 8 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_band4, 4 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_resn, 2 * (size_t)h->O * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W * W + W) * sizeof(double))));
+    h->adj_ready = true;
+    return BPLTV_OK;
+}
+
+// Adjoint gradient of the images (d_u, d_ubar) on the device; result (am*an doubles) -> d_out.
+int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
+                 double* d_out) {
+    int rc = adj_alloc(h);
+    if (rc) return rc;
+    const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
+    const size_t tot = h->tot;
+    const int patch = !(am == 1 && an == 1);
+    const double eps = 2.220446049250313e-16;
+    double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
+    double kact = 1.0 / (patch ? std::sqrt(eps) : eps);  // TVLearningFunctionVec.jl:128 / :245
+    if (kact > kcap) kact = kcap;
+    const int nref = p.refine < 0 ? 3 : p.refine;
+    AdjCoef C;
+    C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;
+    C.h1 = h->d_coef + 4 * tot; C.h2 = h->d_coef + 5 * tot; C.s = h->d_coef + 6 * tot; C.rhs = h->d_coef + 7 * tot;
+    const int gpx = (int)((tot + 255) / 256);
+    const size_t W = (size_t)M + 1;
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N,
+                       O, patch, reg, kact, C);
+    hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
+    hipLaunchKernelGGL(adj_factor_kernel, dim3(O), dim3(1024), (W * W + W) * sizeof(double), h->stream, h->d_band4, M,
+                       N, O, h->d_L, h->d_fail);
+    HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, M, N, h->d_p, (double*)nullptr);
+    for (int it = 0; it < nref; ++it) {
+        hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
+        hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, M, N, h->d_r, h->d_p);
+    }
+    hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
+    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, (int)h->npx, h->d_resn);
+    hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
+                       h->d_gpix);
+    hipLaunchKernelGGL(patch_sum_kernel, dim3(am * an), dim3(256), 0, h->stream, h->d_gpix, M, N, O, am, an, d_out);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    std::vector<int> fail(O);
+    std::vector<double> resn(2 * (size_t)O);
+    HIPCHK(h, hipMemcpyAsync(fail.data(), h->d_fail, sizeof(int) * O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(resn.data(), h->d_resn, sizeof(double) * 2 * O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    h->st.adjoint_ms = ms;
+    h->st.reg_gradient_used = reg;
+    double worst = 0.0;
+    for (int k = 0; k < O; ++k) {
+        if (fail[k] != 0)
+            return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at column %d of image %d",
+                           fail[k] - 1, k);
+        const double r = std::sqrt(resn[2 * k]) / (resn[2 * k + 1] > 0 ? std::sqrt(resn[2 * k + 1]) : 1.0);
+        if (r > worst) worst = r;
+    }
+    h->st.adjoint_residual = worst;
+    return BPLTV_OK;
+}
+
+bpltv_params resolve(const bpltv_params* p) {
+    bpltv_params q;
+    if (p) q = *p; else bpltv_default_params(&q);
+    return q;
+}
+
+struct WallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* pp,
+                    double* u_out, double* d_partial_user, double* partial_host) {
+    if (!h) return BPLTV_E_ARG;
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    int rc = upload_alpha(h, alpha, am, an);
+    if (rc) return rc;
+    rc = run_pdhg(h, p);
+    if (rc) return rc;
+    const double* d_u = h->d_state[h->result_buf][0];
+    HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    rc = compute_cost(h, d_u, h->d_ubar, h->d_partial);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+    const int reg = !(delta > p.delta_t);  // TVLearningFunctionVec.jl:21-25
+    rc = run_gradient(h, d_u, h->d_ubar, reg, p, h->d_partial + 1);
+    if (rc) return rc;
+    const size_t np = 1 + (size_t)am * an;
+    if (d_partial_user)
+        HIPCHK(h, hipMemcpyAsync(d_partial_user, h->d_partial, np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (partial_host)
+        HIPCHK(h, hipMemcpyAsync(partial_host, h->d_partial, np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u_out)
+        HIPCHK(h, hipMemcpyAsync(u_out, d_u, h->tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[4], h->ev[5]));
+    h->st.cost_ms = ms;
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+#pragma GCC visibility push(default)
+extern "C" {
+
+int bpltv_version(void) { return BPLTV_VERSION; }
+
+int bpltv_default_params(bpltv_params* p) {
+    if (!p) return BPLTV_E_ARG;
+    std::memset(p, 0, sizeof(*p));
+    p->rho = 0.0;            // /root/reference/src/TVLearningFunctionVec.jl:34
+    p->tau0 = 5.0;           // :36
+    p->sigma0 = 0.99 / 5;    // :37
+    p->accel = 1;            // :38
+    p->maxiter = 5000;       // :40
+    p->delta_t = 1e-6;       // :14
+    p->check_every = 0;
+    p->gap_tol = 0.0;
+    p->tile_iters = 0;
+    p->use_graph = 1;
+    p->kappa_cap = 0.0;
+    p->refine = -1;
+    return BPLTV_OK;
+}
+
+int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
+    if (!out) return BPLTV_E_ARG;
+    *out = nullptr;
+    if (M < 1 || N < 1 || O < 1 || dtype != 64) return BPLTV_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BPLTV_E_HIP;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return BPLTV_E_HIP;
+    }
+    if (device >= ndev) return BPLTV_E_ARG;
+    bpltv_t* h = new (std::nothrow) bpltv_handle();
+    if (!h) return BPLTV_E_NOMEM;
+    h->M = M; h->N = N; h->O = O; h->device = device;
+    h->npx = (size_t)M * N;
+    h->tot = h->npx * O;
+    std::memset(&h->st, 0, sizeof(h->st));
+    h->st.M = M; h->st.N = N; h->st.O = O; h->st.device = device;
+    h->st.last_gap = -1.0;
+    *out = h;  // returned even on failure below so that bpltv_last_error works; caller destroys
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
+    HIPCHK(h, hipMalloc((void**)&h->d_ubar, h->tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_f, h->tot * sizeof(double)));
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c) HIPCHK(h, hipMalloc((void**)&h->d_state[s][c], h->tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_perimg, (size_t)O * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_scalar, 4 * sizeof(double)));
+    // LDS above 64 KB needs the opt-in attribute
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 32, 32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * 8));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<4, 4, 16, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * 8));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 64, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 32 * 8));
+    return BPLTV_OK;
+}
+
+int bpltv_destroy(bpltv_t* h) {
+    if (!h) return BPLTV_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    for (auto& kv : h->tabs) (void)hipFree(kv.second);
+    void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
+                    h->d_band4, h->d_L, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c)
+            if (h->d_state[s][c]) (void)hipFree(h->d_state[s][c]);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BPLTV_OK;
+}
+
+static int set_data_impl(bpltv_t* h, const double* ubar, const double* f, hipMemcpyKind kind) {
+    if (!h) return BPLTV_E_ARG;
+    if (!ubar || !f) return set_err(h, BPLTV_E_ARG, "set_data: null pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_ubar, ubar, h->tot * sizeof(double), kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_f, f, h->tot * sizeof(double), kind, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->has_data = true;
+    h->has_result = false;
+    return BPLTV_OK;
+}
+
+int bpltv_set_data(bpltv_t* h, const double* ubar, const double* f) {
+    return set_data_impl(h, ubar, f, hipMemcpyHostToDevice);
+}
+
+int bpltv_set_data_device(bpltv_t* h, const double* d_ubar, const double* d_f) {
+    return set_data_impl(h, d_ubar, d_f, hipMemcpyDeviceToDevice);
+}
+
+int bpltv_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out) {
+    if (!h) return BPLTV_E_ARG;
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    int rc = upload_alpha(h, alpha, am, an);
+    if (rc) return rc;
+    rc = run_pdhg(h, p);
+    if (rc) return rc;
+    if (u_out) {
+        HIPCHK(h, hipMemcpyAsync(u_out, h->d_state[h->result_buf][0], h->tot * sizeof(double), hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* p,
+                   double* u_out, double* cost_out, double* grad_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (!cost_out || !grad_out) return set_err(h, BPLTV_E_ARG, "evaluate: null output pointer");
+    if (am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: empty shape");
+    std::vector<double> part(1 + (size_t)am * an);
+    int rc = evaluate_common(h, alpha, am, an, delta, p, u_out, nullptr, part.data());
+    if (rc) return rc;
+    *cost_out = part[0];
+    std::memcpy(grad_out, part.data() + 1, sizeof(double) * (size_t)am * an);
+    return BPLTV_OK;
+}
+
+int bpltv_evaluate_partial(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* p,
+                           double* u_out, double* partial_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (!partial_out) return set_err(h, BPLTV_E_ARG, "evaluate_partial: null output pointer");
+    return evaluate_common(h, alpha, am, an, delta, p, u_out, nullptr, partial_out);
+}
+
+int bpltv_evaluate_device(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* p,
+                          double* d_partial) {
+    if (!h) return BPLTV_E_ARG;
+    if (!d_partial) return set_err(h, BPLTV_E_ARG, "evaluate_device: null output pointer");
+    return evaluate_common(h, alpha, am, an, delta, p, nullptr, d_partial, nullptr);
+}
+
+int bpltv_u_device(bpltv_t* h, const double** d_u) {
+    if (!h || !d_u) return BPLTV_E_ARG;
+    if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
+    *d_u = h->d_state[h->result_buf][0];
+    return BPLTV_OK;
+}
+
+int bpltv_copy_u_device(bpltv_t* h, double* d_dst) {
+    if (!h || !d_dst) return BPLTV_E_ARG;
+    if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(d_dst, h->d_state[h->result_buf][0], h->tot * sizeof(double), hipMemcpyDeviceToDevice,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BPLTV_OK;
+}
+
+int bpltv_duality_gap(bpltv_t* h, double* gap_out) {
+    if (!h || !gap_out) return BPLTV_E_ARG;
+    if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    double gmax = 0.0;
+    int rc = compute_gap(h, gap_out, &gmax);
+    if (rc) return rc;
+    h->st.last_gap = gmax;
+    return BPLTV_OK;
+}
+
+int bpltv_grad_fwd(bpltv_t* h, const double* x, double* d1, double* d2) {
+    if (!h || !x || !d1 || !d2) return BPLTV_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = h->npx;
+    int rc = ensure(h, &h->d_red, &h->red_cap, 3 * n);
+    if (rc) return rc;
+    double* b = h->d_red;
+    HIPCHK(h, hipMemcpyAsync(b, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(grad_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, b, h->M, h->N,
+                       b + n, b + 2 * n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(d1, b + n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d2, b + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BPLTV_OK;
+}
+
+int bpltv_grad_fwd_adjoint(bpltv_t* h, const double* y1, const double* y2, double* out) {
+    if (!h || !y1 || !y2 || !out) return BPLTV_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = h->npx;
+    int rc = ensure(h, &h->d_red, &h->red_cap, 3 * n);
+    if (rc) return rc;
+    double* b = h->d_red;
+    HIPCHK(h, hipMemcpyAsync(b, y1, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b + n, y2, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(grad_fwd_T_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, b, b + n, h->M,
+                       h->N, b + 2 * n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, b + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return BPLTV_OK;
+}
+
+int bpltv_gradient(bpltv_t* h, const double* u, const double* ubar, const double* alpha, int am, int an, int reg,
+                   const bpltv_params* pp, double* grad_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (!u || !ubar || !grad_out) return set_err(h, BPLTV_E_ARG, "gradient: null pointer");
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    int rc = upload_alpha(h, alpha, am, an);
+    if (rc) return rc;
+    if (!h->d_u2) {
+        HIPCHK(h, hipMalloc((void**)&h->d_u2, h->tot * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_ubar2, h->tot * sizeof(double)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_u2, u, h->tot * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ubar2, ubar, h->tot * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = run_gradient(h, h->d_u2, h->d_ubar2, reg ? 1 : 0, p, h->d_partial + 1);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(grad_out, h->d_partial + 1, sizeof(double) * (size_t)am * an, hipMemcpyDeviceToHost,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_stats(bpltv_t* h, bpltv_stats_t* out) {
+    if (!h || !out) return BPLTV_E_ARG;
+    *out = h->st;
+    return BPLTV_OK;
+}
+
+const char* bpltv_last_error(bpltv_t* h) {
+    if (!h) return "null handle";
+    return h->err.c_str();
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

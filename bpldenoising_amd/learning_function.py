@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference's evaluate/solve surface, above the C ABI.
+
+Same names, argument meaning and return shapes as the reference (Julia) so that a caller of
+    tv_op_learning_function(x, data, D; Dt=1e-6, kwargs...) -> (u, cost, grad)
+    denoise(data, x, op; kwargs...)                          -> u
+    TVDenoise(data, parameter)                               -> u
+(/root/reference/src/TVLearningFunctionVec.jl:14-27, :45-70; /root/reference/src/BPLDenoising.jl:41-82)
+can switch to this module; every call goes through libbpltv (HIP, gfx950) -- no CPU path.
+
+Array convention: a Julia `Array{Float64,3}` of size (M, N, O) (column major) is a C-contiguous
+numpy array of shape (O, N, M).  A Julia m x n parameter matrix is a numpy array of shape (n, m).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _alpha_arg(x):
+    a = np.asarray(x, dtype=np.float64)
+    if a.ndim == 0:
+        return np.ascontiguousarray(a.reshape(1)), 1, 1, True
+    if a.ndim == 1:
+        a = a.reshape(1, -1)  # Julia vector of length m == m x 1 matrix
+    if a.ndim != 2:
+        raise ValueError("parameter must be a scalar or a matrix, got ndim=%d" % a.ndim)
+    a = np.ascontiguousarray(a)
+    an, am = a.shape
+    return a, am, an, False
+
+
+class FwdGradientOp:
+    """Marker for the forward-difference gradient operator (Neumann boundary), the only operator
+    the reference passes on this path (/root/reference/src/TVLearningFunctionVec.jl:17)."""
+
+    def __repr__(self):
+        return "FwdGradientOp()"
+
+
+# reference NamedTuple names -> bpltv_params fields
+_PARAM_ALIASES = {
+    "ρ": "rho", "rho": "rho", "τ₀": "tau0", "tau0": "tau0", "σ₀": "sigma0", "sigma0": "sigma0",
+    "accel": "accel", "maxiter": "maxiter", "Δt": "delta_t", "delta_t": "delta_t",
+    "check_every": "check_every", "gap_tol": "gap_tol", "tile_iters": "tile_iters",
+    "use_graph": "use_graph", "kappa_cap": "kappa_cap", "refine": "refine",
+}
+_IGNORED = {"verbose_iter", "save_results", "save_iterations", "op", "α", "alpha"}
+# ^ reference keys with no numerical meaning on this path (TVLearningFunctionVec.jl:39-42)
+
+
+class TVSolver:
+    """One libbpltv handle: O images of size M x N resident on one GPU."""
+
+    def __init__(self, M, N, O, device=-1):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.M, self.N, self.O = int(M), int(N), int(O)
+        rc = self._lib.bpltv_create(C.byref(self._h), self.M, self.N, self.O, int(device), 64)
+        if rc:
+            msg = self._lib.bpltv_last_error(self._h).decode() if self._h else "bpltv_create failed"
+            if self._h:
+                self._lib.bpltv_destroy(self._h)
+                self._h = C.c_void_p()
+            raise _lib.BpltvError(rc, msg)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc:
+            raise _lib.BpltvError(rc, self._lib.bpltv_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            self._lib.bpltv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def params(self, **kw):
+        p = _lib.BpltvParams()
+        self._lib.bpltv_default_params(C.byref(p))
+        variant = kw.pop("variant", None)
+        for k, v in kw.items():
+            if k in _IGNORED:
+                continue
+            if k not in _PARAM_ALIASES:
+                raise TypeError("unknown solver parameter %r" % k)
+            f = _PARAM_ALIASES[k]
+            cur = getattr(p, f)
+            setattr(p, f, type(cur)(v))
+        if variant is not None:
+            p.reserved[0] = int(variant)
+        return p
+
+    def _batch(self, a, what):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim == 2:
+            a = a[None]
+        if a.shape != (self.O, self.N, self.M):
+            raise ValueError("%s has shape %s, expected (O=%d, N=%d, M=%d)" % (what, a.shape, self.O, self.N, self.M))
+        return a
+
+    # -- data ---------------------------------------------------------------------------------
+    def set_data(self, ubar, f):
+        ubar = self._batch(ubar, "ubar")
+        f = self._batch(f, "f")
+        self._check(self._lib.bpltv_set_data(self._h, _ptr(ubar), _ptr(f)))
+
+    def set_data_device(self, ubar_ptr, f_ptr):
+        """Dataset already resident in HBM (raw device pointers, e.g. torch tensor .data_ptr())."""
+        self._check(self._lib.bpltv_set_data_device(self._h, C.c_void_p(ubar_ptr), C.c_void_p(f_ptr)))
+
+    # -- solve --------------------------------------------------------------------------------
+    def denoise(self, x, fetch=True, **kw):
+        a, am, an, _ = _alpha_arg(x)
+        p = self.params(**kw)
+        u = np.empty((self.O, self.N, self.M)) if fetch else None
+        self._check(self._lib.bpltv_denoise(self._h, _ptr(a), am, an, C.byref(p), _ptr(u) if fetch else None))
+        return u
+
+    def evaluate(self, x, delta, fetch_u=True, **kw):
+        a, am, an, scalar = _alpha_arg(x)
+        p = self.params(**kw)
+        u = np.empty((self.O, self.N, self.M)) if fetch_u else None
+        cost = C.c_double(0.0)
+        grad = np.empty(am * an)
+        self._check(self._lib.bpltv_evaluate(self._h, _ptr(a), am, an, float(delta), C.byref(p),
+                                             _ptr(u) if fetch_u else None, C.byref(cost), _ptr(grad)))
+        g = float(grad[0]) if scalar else grad.reshape(an, am)
+        return u, cost.value, g
+
+    def evaluate_partial(self, x, delta, fetch_u=True, **kw):
+        """[cost, grad...] of this handle's images only (to be all-reduced across shards)."""
+        a, am, an, _ = _alpha_arg(x)
+        p = self.params(**kw)
+        u = np.empty((self.O, self.N, self.M)) if fetch_u else None
+        part = np.empty(1 + am * an)
+        self._check(self._lib.bpltv_evaluate_partial(self._h, _ptr(a), am, an, float(delta), C.byref(p),
+                                                     _ptr(u) if fetch_u else None, _ptr(part)))
+        return u, part
+
+    def evaluate_device(self, x, delta, partial_ptr, **kw):
+        """Partial vector written to device memory at `partial_ptr` (1 + am*an doubles)."""
+        a, am, an, _ = _alpha_arg(x)
+        p = self.params(**kw)
+        self._check(self._lib.bpltv_evaluate_device(self._h, _ptr(a), am, an, float(delta), C.byref(p),
+                                                    C.c_void_p(partial_ptr)))
+
+    def gradient(self, u, ubar, x, reg=False, **kw):
+        a, am, an, scalar = _alpha_arg(x)
+        p = self.params(**kw)
+        u = self._batch(u, "u")
+        ubar = self._batch(ubar, "ubar")
+        grad = np.empty(am * an)
+        self._check(self._lib.bpltv_gradient(self._h, _ptr(u), _ptr(ubar), _ptr(a), am, an, int(bool(reg)),
+                                             C.byref(p), _ptr(grad)))
+        return float(grad[0]) if scalar else grad.reshape(an, am)
+
+    def u_device_ptr(self):
+        p = C.c_void_p()
+        self._check(self._lib.bpltv_u_device(self._h, C.byref(p)))
+        return p.value
+
+    def copy_u_device(self, dst_ptr):
+        self._check(self._lib.bpltv_copy_u_device(self._h, C.c_void_p(dst_ptr)))
+
+    def duality_gap(self):
+        g = np.empty(self.O)
+        self._check(self._lib.bpltv_duality_gap(self._h, _ptr(g)))
+        return g
+
+    def grad_fwd(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        d1 = np.empty_like(x); d2 = np.empty_like(x)
+        self._check(self._lib.bpltv_grad_fwd(self._h, _ptr(x), _ptr(d1), _ptr(d2)))
+        return d1, d2
+
+    def grad_fwd_adjoint(self, y1, y2):
+        y1 = np.ascontiguousarray(y1, dtype=np.float64)
+        y2 = np.ascontiguousarray(y2, dtype=np.float64)
+        out = np.empty_like(y1)
+        self._check(self._lib.bpltv_grad_fwd_adjoint(self._h, _ptr(y1), _ptr(y2), _ptr(out)))
+        return out
+
+    def stats(self):
+        s = _lib.BpltvStats()
+        self._check(self._lib.bpltv_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-named entry points.  The solver (and the dataset upload) is cached per dataset object,
+# because bilevel_learn passes the same `ds` to every evaluation (/root/reference/src/TRBox.jl:210,227).
+# ---------------------------------------------------------------------------------------------
+_cache = {}
+
+
+def _solver_for(ubar, f):
+    f = np.asarray(f)
+    if f.ndim == 2:
+        f = f[None]
+    O, N, M = f.shape
+    key = (id(ubar), id(f), f.shape)
+    ent = _cache.get("s")
+    if ent is None or ent[0] != key:
+        if ent is not None:
+            ent[1].close()
+        s = TVSolver(M, N, O)
+        s.set_data(f if ubar is None else ubar, f)
+        _cache["s"] = (key, s, ubar, f)  # keep the arrays alive so that id() stays unique
+        ent = _cache["s"]
+    return ent[1]
+
+
+def tv_op_learning_function(x, data, Δ, Δt=1e-6, **kwargs):
+    """(u, cost, grad) -- /root/reference/src/TVLearningFunctionVec.jl:14-27.
+
+    data = (ubar, f); grad has the type/shape of x (float for scalar x, (n, m) array otherwise)."""
+    ubar, f = data[0], data[1]
+    s = _solver_for(ubar, f)
+    return s.evaluate(x, Δ, delta_t=Δt, **kwargs)
+
+
+def denoise(data, x, op=None, **kwargs):
+    """u = denoise(f, x, op; kwargs...) -- /root/reference/src/TVLearningFunctionVec.jl:45-70.
+    The array-x method of the reference takes no kwargs (:57); they are accepted here for both."""
+    if op is not None and not isinstance(op, FwdGradientOp):
+        raise TypeError("only FwdGradientOp is supported on this path")
+    s = _solver_for(None, data)
+    return s.denoise(x, **kwargs)
+
+
+def TVDenoise(data, parameter, **kwargs):
+    """/root/reference/src/BPLDenoising.jl:41-82: the same solve with maxiter = 10000."""
+    kwargs.setdefault("maxiter", 10000)
+    return denoise(data, parameter, FwdGradientOp(), **kwargs)
+
+
+def L2CostFunction(u, true_):
+    """0.5*norm2^2(u - true) -- /root/reference/src/BPLDenoising.jl:84-86 (host arithmetic on
+    results already fetched; inside evaluate the loss is reduced on the GPU)."""
+    d = np.asarray(u, dtype=np.float64) - np.asarray(true_, dtype=np.float64)
+    return 0.5 * float(np.sum(d * d))

@@ -1,0 +1,147 @@
+/*
+ * bpltv.h -- C ABI of libbpltv: the MI355X (gfx950) inner TV-denoising solver that drops in behind
+ * BPLDenoising's evaluate/solve surface.
+ *
+ * What it replaces in the reference (dvillacis/BPLDenoising, all paths relative to its root):
+ *   src/TVLearningFunctionVec.jl:14-27   tv_op_learning_function(x, data, D) -> (u, cost, grad)
+ *   src/TVLearningFunctionVec.jl:45-70   denoise(data, x::Real|AbstractArray, op)
+ *   src/BPLDenoising.jl:41-82            TVDenoise(data, parameter)          (maxiter = 10000)
+ *   src/TVLearningFunctionVec.jl:72-254  gradient / gradient_reg (adjoint state, per image)
+ * and, inside those, the external VariationalImaging.op_denoise_pdps loop they call
+ * (src/TVLearningFunctionVec.jl:52,67).  The caller -- bilevel_learn, src/TRBox.jl:36,46,227 --
+ * is untouched: it only sees a function (x, data, D) -> (u, cost, grad).
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only.  Every function returns 0 on success or a BPLTV_E_* code;
+ *     bpltv_last_error() gives the message.  Nothing throws, prints, or exits.
+ *   - Images are Julia `Array{Float64,3}` of size (M, N, O), column major: element (i, j, k) at
+ *     i + M*j + M*N*k.  data[1] = ubar (ground truth), data[2] = f (noisy), src/TVLearningFunctionVec.jl:15-16.
+ *   - The parameter x is passed as (alpha, am, an), column major am x an:
+ *        1 x 1  scalar alpha;  m x n patch parameter (upsampled piecewise-constant, PatchOp);
+ *        M x N  per-pixel map.   grad has the same shape (src/TRBox.jl:37-39,167,237).
+ *   - Host pointers are read/written during the call only; the library keeps no host pointer.
+ *     One call in flight per handle; calls block until the device work is complete.
+ *   - One handle drives one GPU.  Multi-GPU = one process (or handle) per GPU, images sharded by
+ *     the host layer, one all-reduce of the [cost, grad...] partial vector (bpltv_evaluate_partial /
+ *     bpltv_evaluate_device); see INTEGRATION.md.
+ */
+#ifndef BPLTV_H
+#define BPLTV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPLTV_VERSION 1
+
+enum {
+    BPLTV_OK = 0,
+    BPLTV_E_ARG = 1,      /* bad argument (null pointer, size mismatch, unsupported shape)   */
+    BPLTV_E_HIP = 2,      /* HIP runtime error (message holds hipGetErrorString)             */
+    BPLTV_E_NODATA = 3,   /* evaluate/denoise before set_data                                */
+    BPLTV_E_NUMERIC = 4,  /* adjoint factorisation broke down (non-positive pivot)           */
+    BPLTV_E_NOMEM = 5,
+    BPLTV_E_UNSUPPORTED = 6
+};
+
+typedef struct bpltv_handle bpltv_t;
+
+/* The solver NamedTuple of src/TVLearningFunctionVec.jl:33-43 (+ the learning function's Dt). */
+typedef struct bpltv_params {
+    double rho;          /* Huber smoothing of the TV term; reference 0                           */
+    double tau0;         /* reference 5                                                           */
+    double sigma0;       /* reference 0.99/5                                                      */
+    int accel;           /* reference true                                                        */
+    int maxiter;         /* reference 5000 (TVDenoise: 10000); fixed count, no early stop         */
+    double delta_t;      /* reference 1e-6: D > delta_t -> gradient, else gradient_reg            */
+    int check_every;     /* > 0: evaluate the duality gap every check_every iterations            */
+    double gap_tol;      /* > 0 with check_every > 0: stop once max-image gap <= gap_tol.
+                            0 = reference behaviour (always maxiter iterations)                   */
+    int tile_iters;      /* PDHG iterations fused per kernel launch (temporal blocking depth);
+                            0 = library default for the image size                                */
+    int use_graph;       /* 1 (default): replay the launch sequence from a hipGraph               */
+    double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
+    int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3)   */
+    int reserved[5];
+} bpltv_params;
+
+typedef struct bpltv_stats {
+    int M, N, O, device;
+    int iterations;            /* PDHG iterations executed by the last denoise/evaluate          */
+    int launches;              /* PDHG kernel launches of that call                               */
+    int tile_iters;            /* fused iterations per launch actually used                       */
+    int tiles;                 /* workgroups per PDHG launch                                      */
+    int graph_used;
+    double pdhg_ms;            /* HIP-event time of the PDHG launch sequence (device)            */
+    double cost_ms;
+    double adjoint_ms;         /* HIP-event time of the adjoint gradient (all images)            */
+    double total_ms;           /* host wall time of the last call                                 */
+    double bytes_per_px_iter;  /* algorithmic bytes: 56 (scalar/patch alpha) or 64 (alpha map)    */
+    double algorithmic_bytes;  /* bytes_per_px_iter * M*N*O * iterations                          */
+    double last_gap;           /* max over images of the duality gap if it was computed, else -1  */
+    double adjoint_residual;   /* max over images of ||rhs - A p|| / ||rhs|| after refinement     */
+    int reg_gradient_used;     /* 1 if the last evaluate took the gradient_reg branch             */
+    int reserved[7];
+} bpltv_stats_t;
+
+/* Fill *p with the reference defaults (src/TVLearningFunctionVec.jl:33-43, delta_t 1e-6). */
+int bpltv_default_params(bpltv_params *p);
+
+/* Create a solver for O images of size M x N on HIP device `device` (-1 = current device).
+ * dtype: 64 (Float64, the reference's arithmetic, src/TVLearningFunctionVec.jl:8-9). */
+int bpltv_create(bpltv_t **h, int M, int N, int O, int device, int dtype);
+int bpltv_destroy(bpltv_t *h);
+
+/* Upload the dataset (ubar, f) once; it is identical for every evaluation of a run
+ * (src/TRBox.jl:210,227 pass the same `ds`).  Host pointers. */
+int bpltv_set_data(bpltv_t *h, const double *ubar, const double *f);
+/* Same, from buffers already resident in HBM (device pointers, copied device-to-device). */
+int bpltv_set_data_device(bpltv_t *h, const double *d_ubar, const double *d_f);
+
+/* denoise(data, x, op; kwargs...): src/TVLearningFunctionVec.jl:45-70, src/BPLDenoising.jl:41-82.
+ * u_out: host, M*N*O doubles, or NULL to leave the result on the device (bpltv_u_device). */
+int bpltv_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_params *p,
+                  double *u_out);
+
+/* tv_op_learning_function(x, data, D): src/TVLearningFunctionVec.jl:14-27.
+ * cost_out: 1 double; grad_out: am*an doubles; u_out: host M*N*O doubles or NULL. */
+int bpltv_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta,
+                   const bpltv_params *p, double *u_out, double *cost_out, double *grad_out);
+
+/* Sharded form: this handle's images only.  partial_out (host, 1 + am*an doubles) receives
+ * [cost, grad...] summed over the handle's O images; the caller all-reduces it across shards
+ * (cost and grad are plain sums over images: src/TVLearningFunctionVec.jl:20,80,172). */
+int bpltv_evaluate_partial(bpltv_t *h, const double *alpha, int am, int an, double delta,
+                           const bpltv_params *p, double *u_out, double *partial_out);
+/* Same with the partial vector written to device memory (d_partial: 1 + am*an doubles in HBM),
+ * ready for an RCCL all-reduce without a host round trip. */
+int bpltv_evaluate_device(bpltv_t *h, const double *alpha, int am, int an, double delta,
+                          const bpltv_params *p, double *d_partial);
+
+/* Device pointer of the last primal result u (M*N*O doubles, valid until the next call). */
+int bpltv_u_device(bpltv_t *h, const double **d_u);
+/* Copy the last primal result to a device buffer owned by the caller. */
+int bpltv_copy_u_device(bpltv_t *h, double *d_dst);
+
+/* Duality gap of the last solve per image (host, O doubles): gap_k >= 0.5*||u_k - u*_k||^2. */
+int bpltv_duality_gap(bpltv_t *h, double *gap_out);
+
+/* FwdGradientOp and its adjoint on the device (src/TVLearningFunctionVec.jl:17; matrix form
+ * :106).  Host pointers, one M x N image; d1/d2 are the two stacked components. */
+int bpltv_grad_fwd(bpltv_t *h, const double *x, double *d1, double *d2);
+int bpltv_grad_fwd_adjoint(bpltv_t *h, const double *y1, const double *y2, double *out);
+
+/* Adjoint gradient alone for given (u, ubar) held by the caller (host, M*N*O each):
+ * gradient (reg = 0, src/TVLearningFunctionVec.jl:98-135,219-254) or gradient_reg (reg = 1,
+ * :137-161,192-215), summed over the O images as the batch wrappers do (:72-96,163-190). */
+int bpltv_gradient(bpltv_t *h, const double *u, const double *ubar, const double *alpha, int am,
+                   int an, int reg, const bpltv_params *p, double *grad_out);
+
+int bpltv_stats(bpltv_t *h, bpltv_stats_t *out);
+const char *bpltv_last_error(bpltv_t *h);
+int bpltv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPLTV_H */

@@ -1,0 +1,180 @@
+"""ctypes binding of oracle/libbpltv_oracle.so  --  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+Arrays follow the C ABI convention: numpy (O, N, M) C-contiguous == Julia (M, N, O) column major.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbpltv_oracle.so")
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "bpltv_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbpltv_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.bplo_step_table.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, _dp]
+        L.bplo_step_table.restype = None
+        L.bplo_pdhg.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                                C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
+        L.bplo_pdhg.restype = C.c_int
+        L.bplo_cost.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.bplo_cost.restype = C.c_double
+        L.bplo_gap.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        L.bplo_gap.restype = None
+        L.bplo_grad_fwd.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.bplo_grad_fwd_T.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.bplo_patch_upsample.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.bplo_patch_adjoint.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.bplo_gradient_image.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int,
+                                          C.c_double, C.c_int, _dp, _dp, _dp]
+        L.bplo_gradient_image.restype = C.c_int
+        L.bplo_gradient.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, C.c_int, _dp, _dp]
+        L.bplo_gradient.restype = C.c_int
+        L.bplo_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def alpha_arg(alpha):
+    """-> (array, am, an): scalar -> 1x1; numpy (an, am) array == column-major am x an."""
+    a = np.asarray(alpha, dtype=np.float64)
+    if a.ndim == 0:
+        return a.reshape(1), 1, 1
+    a = np.ascontiguousarray(a)
+    an, am = a.shape
+    return a, am, an
+
+
+def step_table(maxiter, tau0=5.0, sigma0=0.99 / 5, accel=True):
+    tab = np.empty((maxiter, 5))
+    lib().bplo_step_table(maxiter, tau0, sigma0, int(accel), _p(tab))
+    return tab
+
+
+def pdhg(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True, nthreads=1,
+         return_dual=False):
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3)
+    y1 = np.empty_like(f3) if return_dual else None
+    y2 = np.empty_like(f3) if return_dual else None
+    rc = lib().bplo_pdhg(M, N, O, _p(f3), _p(a), am, an, rho, tau0, sigma0, int(accel), maxiter,
+                         _p(x), _p(y1), _p(y2), nthreads)
+    if rc:
+        raise RuntimeError("bplo_pdhg rc=%d" % rc)
+    x = x.reshape(f.shape)
+    if return_dual:
+        return x, y1.reshape(f.shape), y2.reshape(f.shape)
+    return x
+
+
+def cost(u, ubar, per_image=False):
+    u = _c(u); ubar = _c(ubar)
+    u3 = u.reshape((-1,) + u.shape[-2:])
+    O, N, M = u3.shape
+    pi = np.empty(O)
+    tot = lib().bplo_cost(M, N, O, _p(u3), _p(ubar), _p(pi))
+    return (tot, pi) if per_image else tot
+
+
+def gap(u, y1, y2, f, alpha):
+    u = _c(u); y1 = _c(y1); y2 = _c(y2); f = _c(f)
+    u3 = u.reshape((-1,) + u.shape[-2:])
+    O, N, M = u3.shape
+    a, am, an = alpha_arg(alpha)
+    out = np.empty(O)
+    lib().bplo_gap(M, N, O, _p(u3), _p(y1), _p(y2), _p(f), _p(a), am, an, _p(out))
+    return out
+
+
+def grad_fwd(x):
+    x = _c(x); N, M = x.shape
+    d1 = np.empty_like(x); d2 = np.empty_like(x)
+    lib().bplo_grad_fwd(M, N, _p(x), _p(d1), _p(d2))
+    return d1, d2
+
+
+def grad_fwd_T(y1, y2):
+    y1 = _c(y1); y2 = _c(y2); N, M = y1.shape
+    r = np.empty_like(y1)
+    lib().bplo_grad_fwd_T(M, N, _p(y1), _p(y2), _p(r))
+    return r
+
+
+def patch_upsample(alpha, M, N):
+    a, am, an = alpha_arg(alpha)
+    out = np.empty((N, M))
+    lib().bplo_patch_upsample(_p(a), am, an, M, N, _p(out))
+    return out
+
+
+def patch_adjoint(g, am, an):
+    g = _c(g); N, M = g.shape
+    out = np.empty((an, am))
+    lib().bplo_patch_adjoint(_p(g), M, N, am, an, _p(out))
+    return out
+
+
+def gradient_image(u, ubar, amap, patch=False, reg=False, kappa_cap=1e12, nref=2):
+    u = _c(u); ubar = _c(ubar); amap = _c(amap)
+    N, M = u.shape
+    gpix = np.empty_like(u); p = np.empty_like(u)
+    res = C.c_double(0.0)
+    rc = lib().bplo_gradient_image(M, N, _p(u), _p(ubar), _p(amap), int(patch), int(reg), kappa_cap, nref,
+                                   _p(gpix), _p(p), C.byref(res))
+    if rc:
+        raise RuntimeError("bplo_gradient_image rc=%d" % rc)
+    return gpix, p, res.value
+
+
+def gradient(alpha, u, ubar, reg=False, kappa_cap=1e12, nref=2, per_image=False):
+    u = _c(u); ubar = _c(ubar)
+    O, N, M = u.shape
+    a, am, an = alpha_arg(alpha)
+    out = np.empty(am * an)
+    pi = np.empty((O, am * an))
+    rc = lib().bplo_gradient(M, N, O, _p(u), _p(ubar), _p(a), am, an, int(reg), kappa_cap, nref, _p(out), _p(pi))
+    if rc:
+        raise RuntimeError("bplo_gradient rc=%d" % rc)
+    g = float(out[0]) if (am == 1 and an == 1) else out.reshape(an, am)
+    return (g, pi) if per_image else g
+
+
+def tv_op_learning_function(x, data, delta, delta_t=1e-6, maxiter=5000, rho=0.0, tau0=5.0,
+                            sigma0=0.99 / 5, accel=True, nthreads=1):
+    """(u, cost, grad) of /root/reference/src/TVLearningFunctionVec.jl:14-27, C restatement."""
+    ubar, f = data
+    u = pdhg(f, x, maxiter=maxiter, rho=rho, tau0=tau0, sigma0=sigma0, accel=accel, nthreads=nthreads)
+    c = cost(u, ubar)
+    g = gradient(x, u, ubar, reg=not (delta > delta_t))
+    return u, c, g
+
+
+def max_threads():
+    return lib().bplo_max_threads()
