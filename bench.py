@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- PDHG iterations/sec of the batched TV-denoising hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1: launched by
+torch.distributed.run, one rank per GPU).  One *step* = one pass of the hot path over one batch:
+`denoise` of the resident batch with the reference's fixed iteration count (5000 PDHG iterations,
+/root/reference/src/TVLearningFunctionVec.jl:40), inputs already in HBM, result left in HBM.
+
+Workload (BASELINE.json configs[1] / north_star): 10 x 128 x 128 Float64 images, scalar alpha.
+Scaling: "weak" (default) -- every rank owns its own 10-image batch (images are independent ROF
+problems; no data-path collective); value = batches * iterations / time summed over ranks.
+`--scaling strong` shards ONE 10-image batch over the ranks (2,2,1,1,... for N = 8) and adds the
+per-evaluation all-reduce of [cost, grad] (`--evaluate`).
+
+Rank 0 prints one JSON line with `roofline` (dominant kernel pdhg_tile_kernel, HBM-bound
+accounting: 56 B per pixel per iteration) and `cpu_baseline` (the oracle's C restatement timed on
+the host cores: kind "port" -- the reference is Julia and cannot run here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def synth_batch(O, N, M, seed=20211004):
+    """Synthetic stand-in for cameraman/faces: piecewise-smooth truth in [0,1],
+    f = round(255*clip(truth + N(0, 0.1^2), 0, 1))/255."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+    ub = np.zeros((O, N, M))
+    for k in range(O):
+        img = 0.3 + 0.4 * (ii / M) * rng.random() + 0.2 * (jj / N) * rng.random()
+        for _ in range(6):
+            ci, cj, r = rng.random() * M, rng.random() * N, (0.05 + 0.2 * rng.random()) * min(M, N)
+            img = np.where((ii - ci) ** 2 + (jj - cj) ** 2 < r * r, rng.random(), img)
+        ub[k] = np.clip(img, 0, 1)
+    f = np.round(255 * np.clip(ub + 0.1 * rng.standard_normal(ub.shape), 0, 1)) / 255
+    return ub, f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=5000, help="PDHG iterations per step (reference: 5000)")
+    ap.add_argument("--images", type=int, default=10)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--alpha", type=float, default=0.1)
+    ap.add_argument("--alpha-map", action="store_true", help="spatially varying alpha (64 B/px/iter)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--evaluate", action="store_true", help="time full evaluate (loss + adjoint gradient + all-reduce)")
+    ap.add_argument("--tile-iters", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0 = auto)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bpldenoising_amd import TVSolver, shard_range
+
+    M = N = args.size
+    if args.scaling == "weak":
+        O_local, seed = args.images, 20211004 + rank
+        lo = 0
+    else:
+        lo, hi = shard_range(args.images, world, rank)
+        O_local, seed = hi - lo, 20211004
+    ub_full, f_full = synth_batch(args.images, N, M, seed)
+    ub, f = (ub_full, f_full) if args.scaling == "weak" else (ub_full[lo:lo + O_local], f_full[lo:lo + O_local])
+    if args.alpha_map:
+        jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+        alpha = 0.11 + 0.09 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
+    else:
+        alpha = args.alpha
+
+    solver = None
+    kw = dict(maxiter=args.iters, tile_iters=args.tile_iters, use_graph=0 if args.no_graph else 1)
+    if args.variant:
+        kw["variant"] = args.variant
+    if O_local > 0:
+        solver = TVSolver(M, N, O_local, device=local_rank)
+        t_ub = torch.from_numpy(ub).cuda()
+        t_f = torch.from_numpy(f).cuda()
+        torch.cuda.synchronize()
+        solver.set_data_device(t_ub.data_ptr(), t_f.data_ptr())  # inputs resident in HBM
+    part = torch.zeros(2 if not args.alpha_map else 1 + M * N, dtype=torch.float64, device="cuda")
+
+    def step():
+        if args.evaluate:
+            part.zero_()
+            if solver is not None:
+                solver.evaluate_device(alpha, 0.1, part.data_ptr(), **kw)
+            if world > 1:
+                dist.all_reduce(part)
+        elif solver is not None:
+            solver.denoise(alpha, fetch=False, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev_ms, ev_launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if solver is not None:
+            st = solver.stats()
+            ev_ms += st["pdhg_ms"]          # HIP events on the library's own stream
+            ev_launches += st["launches"]
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    T = float(tmax.item())
+
+    if rank == 0:
+        st = solver.stats()
+        batches = world if args.scaling == "weak" else 1
+        value = batches * args.steps * args.iters / T
+        bytes_px = st["bytes_per_px_iter"]
+        launch_us = 1e3 * ev_ms / max(ev_launches, 1)
+        bytes_per_launch = bytes_px * M * N * O_local * (args.iters / max(st["launches"], 1))
+        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):  # PMC-derived HBM bytes per launch, written from a separate --pmc run
+            try:
+                tj = json.load(open(tf))
+                if tj.get("workload") == "%dx%dx%d" % (args.images, N, M) and not args.alpha_map:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "PDHG iters/sec (batched 128x128 images)",
+            "value": value,
+            "unit": "PDHG iterations/s of a %dx%dx%d f64 batch%s" % (
+                args.images, N, M, " per GPU, summed over GPUs" if args.scaling == "weak" and world > 1 else ""),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * T / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d f64 batch, %s alpha, %d PDHG iterations per step (%s)" % (
+                           args.images, N, M, "per-pixel" if args.alpha_map else "scalar", args.iters,
+                           "evaluate: loss + adjoint gradient + all-reduce" if args.evaluate else "denoise"),
+                       "images_per_gpu": O_local, "tile_iters": st["tile_iters"], "tiles_per_launch": st["tiles"],
+                       "launches_per_step": st["launches"], "hipgraph": bool(st["graph_used"]),
+                       "parallelism": "images sharded, dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "pdhg_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
+                         "bytes_per_px_iter": bytes_px},
+            "pdhg_event_ms_per_step": ev_ms / args.steps,
+        }
+        if not args.no_cpu_baseline:
+            from oracle import c_oracle as co
+            cpu_iters = args.cpu_iters or min(args.iters, 5000 if M * N * args.images <= 200000 else 20)
+            fb = f_full if args.scaling == "weak" else f_full
+            t1 = time.perf_counter()
+            co.pdhg(fb, alpha, maxiter=cpu_iters, nthreads=1)
+            c1 = time.perf_counter() - t1
+            nth = max(1, min(co.max_threads(), os.cpu_count() or 1, args.images))
+            t1 = time.perf_counter()
+            co.pdhg(fb, alpha, maxiter=cpu_iters, nthreads=nth)
+            cn = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": cpu_iters / c1, "unit": "PDHG iterations/s of the same %dx%dx%d batch" % (args.images, N, M),
+                "cores": 1, "kind": "port",
+                "sample": "%d iterations of the full batch, oracle/bpltv_oracle.c (gcc -O2), 1 thread (stock Julia runs the reference serially)" % cpu_iters,
+                "all_cores": {"value": cpu_iters / cn, "cores": nth, "note": "OpenMP over images"},
+                "host_cpus": os.cpu_count(),
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

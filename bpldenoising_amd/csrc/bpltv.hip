@@ -28,6 +28,8 @@ namespace {
 struct Variant {
     int RI, RJ, threads;
     void (*launch)(const PdhgArgs&, int grid, hipStream_t);
+    const void* func;  // kernel symbol, for hipGraphAddKernelNode
+    size_t lds;
     const char* name;
 };
 
@@ -37,8 +39,10 @@ void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((pdhg_tile_kernel<PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
 }
 
-#define VAR(PI, PJ, TI, TJ) \
-    { PI * TI, PJ * TJ, TI * TJ, &launch_variant<PI, PJ, TI, TJ>, #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
+#define VAR(PI, PJ, TI, TJ)                                                                    \
+    { PI * TI, PJ * TJ, TI * TJ, &launch_variant<PI, PJ, TI, TJ>,                               \
+      reinterpret_cast<const void*>(&pdhg_tile_kernel<PI, PJ, TI, TJ>),                         \
+      sizeof(double) * 3 * (PI * TI) * (PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread   (large images, deep blocking)
@@ -54,12 +58,12 @@ const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 struct GraphKey {
-    int maxiter, T, variant, am, an;
+    int maxiter, T, variant, am, an, chains;
     double rho, tau0, sigma0;
     int accel;
     bool operator<(const GraphKey& o) const {
-        return std::tie(maxiter, T, variant, am, an, rho, tau0, sigma0, accel) <
-               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.rho, o.tau0, o.sigma0, o.accel);
+        return std::tie(maxiter, T, variant, am, an, chains, rho, tau0, sigma0, accel) <
+               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.chains, o.rho, o.tau0, o.sigma0, o.accel);
     }
 };
 
@@ -94,7 +98,9 @@ struct bpltv_handle {
     double* d_perimg = nullptr;   // [O] cost per image / gap per image
     double* d_scalar = nullptr;   // [4]
     std::map<TabKey, double*> tabs;
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, std::vector<hipGraphExec_t>> graphs;  // one exec per chain
+    std::vector<hipStream_t> chain_streams;
+    std::vector<hipEvent_t> chain_events;
     // adjoint workspace (lazy)
     bool adj_ready = false;
     double* d_coef = nullptr;   // 8 planes
@@ -178,7 +184,8 @@ int get_table(bpltv_t* h, const bpltv_params& p, double** out) {
 }
 
 void drop_graphs(bpltv_t* h) {
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->graphs)
+        for (auto e : kv.second) (void)hipGraphExecDestroy(e);
     h->graphs.clear();
 }
 
@@ -203,7 +210,7 @@ int upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
 }
 
 struct Plan {
-    int variant, T, nTi, nTj, grid;
+    int variant, T, nTi, nTj, grid, chains;
 };
 
 int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
@@ -213,7 +220,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
     const Variant& V = kVariants[v];
     int T = p.tile_iters;
-    if (T <= 0) T = (V.RI >= 64 && V.RJ >= 64) ? 8 : 4;
+    if (T <= 0) T = 8;  // measured best on MI355X for both the 32x32 and the 64x64 region (profiles/)
     // the halo must leave a core when the image is larger than the region
     auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
     int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
@@ -225,7 +232,74 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     pl->nTj = tile_count(N, V.RJ, T);
     if (pl->nTi < 1 || pl->nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
     pl->grid = pl->nTi * pl->nTj * h->O;
+    // Independent image groups ("chains") of the launch graph: images never exchange data, so
+    // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
+    // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
+    int ch = p.reserved[1];
+    if (ch <= 0) ch = (h->npx <= 256 * 256 && h->O >= 2) ? 2 : 1;  // two queues overlap launch latency
+    if (ch > h->O) ch = h->O;
+    pl->chains = ch;
     return BPLTV_OK;
+}
+
+// Build one hipGraph per chain (image group): maxiter iterations as a linear launch sequence.
+// The chains are replayed concurrently, each on its own stream (= its own hardware queue).
+int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab,
+                 std::vector<hipGraphExec_t>* out) {
+    const Variant& V = kVariants[pl.variant];
+    const int tilesPerImg = pl.nTi * pl.nTj;
+    int rc = BPLTV_OK;
+    for (int c = 0; c < pl.chains && rc == BPLTV_OK; ++c) {
+        const int lo = (int)(((long)h->O * c) / pl.chains), hi = (int)(((long)h->O * (c + 1)) / pl.chains);
+        if (hi <= lo) continue;
+        hipGraph_t g = nullptr;
+        HIPCHK(h, hipGraphCreate(&g, 0));
+        hipGraphNode_t prev = nullptr;
+        int cur = 0;
+        for (int it = 0; it < p.maxiter; it += pl.T) {
+            PdhgArgs a;
+            a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
+            a.am = h->last_am; a.an = h->last_an;
+            a.M = h->M; a.N = h->N; a.O = h->O;
+            a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
+            a.img0 = lo;
+            const int nxt = (it == 0) ? 0 : 1 - cur;
+            a.first = (it == 0) ? 1 : 0;
+            a.xin = h->d_state[cur][0]; a.y1in = h->d_state[cur][1]; a.y2in = h->d_state[cur][2];
+            a.xout = h->d_state[nxt][0]; a.y1out = h->d_state[nxt][1]; a.y2out = h->d_state[nxt][2];
+            a.it0 = it;
+            a.nit = std::min(pl.T, p.maxiter - it);
+            void* kargs[] = {&a};
+            hipKernelNodeParams kp;
+            std::memset(&kp, 0, sizeof(kp));
+            kp.func = const_cast<void*>(V.func);
+            kp.gridDim = dim3(tilesPerImg * (hi - lo));
+            kp.blockDim = dim3(V.threads);
+            kp.sharedMemBytes = (unsigned)V.lds;
+            kp.kernelParams = kargs;
+            kp.extra = nullptr;
+            hipGraphNode_t node = nullptr;
+            hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+            if (e != hipSuccess) {
+                rc = set_err(h, BPLTV_E_HIP, "hipGraphAddKernelNode: %s", hipGetErrorString(e));
+                break;
+            }
+            prev = node;
+            cur = nxt;
+        }
+        if (rc == BPLTV_OK) {
+            hipGraphExec_t ex = nullptr;
+            hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            if (e != hipSuccess) rc = set_err(h, BPLTV_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            else out->push_back(ex);
+        }
+        (void)hipGraphDestroy(g);
+    }
+    if (rc != BPLTV_OK) {
+        for (auto e : *out) (void)hipGraphExecDestroy(e);
+        out->clear();
+    }
+    return rc;
 }
 
 // Enqueue PDHG iterations [it0, it1) on the stream.  *buf: state set holding the current iterate
@@ -242,6 +316,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.an = h->last_an;
     a.M = h->M; a.N = h->N; a.O = h->O;
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
+    a.img0 = 0;
     int cur = *buf;
     for (int it = it0; it < it1; it += pl.T) {
         const int nit = std::min(pl.T, it1 - it);
@@ -313,33 +388,40 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (!chunked) {
         bool done = false;
         if (p.use_graph) {
-            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0};
+            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0};
             auto it = h->graphs.find(key);
-            hipGraphExec_t exec = nullptr;
             const int nl = (p.maxiter + pl.T - 1) / pl.T;
             if (it == h->graphs.end()) {
-                hipGraph_t g = nullptr;
-                hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
-                if (e == hipSuccess) {
-                    int b2 = 0, l2 = 0;
-                    int rc2 = enqueue_pdhg(h, p, pl, d_tab, 0, p.maxiter, &b2, &l2);
-                    e = hipStreamEndCapture(h->stream, &g);
-                    if (rc2 == BPLTV_OK && e == hipSuccess && g) {
-                        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-                        if (e == hipSuccess) h->graphs[key] = exec; else exec = nullptr;
-                    }
-                    if (g) (void)hipGraphDestroy(g);
+                std::vector<hipGraphExec_t> ex;
+                if (build_graphs(h, p, pl, d_tab, &ex) == BPLTV_OK && !ex.empty()) {
+                    h->graphs[key] = ex;
+                    it = h->graphs.find(key);
                 }
                 (void)hipGetLastError();
-            } else {
-                exec = it->second;
             }
-            if (exec) {
-                // the capture left the stream's event record outside the graph; record again
-                HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-                HIPCHK(h, hipGraphLaunch(exec, h->stream));
+            if (it != h->graphs.end()) {
+                const std::vector<hipGraphExec_t>& ex = it->second;
+                if (ex.size() == 1) {
+                    HIPCHK(h, hipGraphLaunch(ex[0], h->stream));
+                } else {
+                    while (h->chain_streams.size() < ex.size()) {
+                        hipStream_t cs = nullptr;
+                        hipEvent_t ce = nullptr;
+                        HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                        HIPCHK(h, hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+                        h->chain_streams.push_back(cs);
+                        h->chain_events.push_back(ce);
+                    }
+                    for (size_t c = 0; c < ex.size(); ++c) {  // fork: every chain waits for ev[0]
+                        HIPCHK(h, hipStreamWaitEvent(h->chain_streams[c], h->ev[0], 0));
+                        HIPCHK(h, hipGraphLaunch(ex[c], h->chain_streams[c]));
+                        HIPCHK(h, hipEventRecord(h->chain_events[c], h->chain_streams[c]));
+                    }
+                    for (size_t c = 0; c < ex.size(); ++c)  // join
+                        HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[c], 0));
+                }
                 buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
-                launches = nl;
+                launches = nl * (int)ex.size();
                 h->st.graph_used = 1;
                 done = true;
             }
@@ -586,6 +668,8 @@ int bpltv_destroy(bpltv_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
+    for (auto cs : h->chain_streams) (void)hipStreamDestroy(cs);
+    for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
                     h->d_band4, h->d_L, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};

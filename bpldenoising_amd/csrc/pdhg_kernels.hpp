@@ -4,8 +4,8 @@
 //
 // Replaces the external `op_denoise_pdps` loop called at
 // /root/reference/src/TVLearningFunctionVec.jl:52,67 (constants :33-43) and
-// /root/reference/src/BPLDenoising.jl:56,79.  Arithmetic = "spec v1" of oracle/bpltv_oracle.c,
-// reproduced bit for bit (explicit fma only; build with -ffp-contract=off; IEEE f64 div/sqrt).
+// /root/reference/src/BPLDenoising.jl:56,79.  Arithmetic = "spec v2" of oracle/bpltv_oracle.c,
+// reproduced bit for bit (explicit fma only; build with -ffp-contract=off).
 //
 // Design (MI355X): one workgroup owns one tile of one image.  It loads the tile plus a halo of
 // `halo` pixels (x, y1, y2, f: registers), runs `nit <= halo` full PDHG iterations on chip --
@@ -39,6 +39,7 @@ struct PdhgArgs {
     int M, N, O;
     int nTi, nTj, halo;
     int first;  // 1: start from x = f, y = 0 (inputs xin/y1in/y2in ignored)
+    int img0;   // first image handled by this launch (grid = tiles per image * images of the chain)
 };
 
 // 1-D tiling with halo: region length R, halo T, image length L.  Tile a covers region
@@ -78,6 +79,22 @@ __device__ __forceinline__ double alpha_at(const double* __restrict__ alpha, int
     return alpha[(int)(((long)i * am) / M) + (size_t)am * (int)(((long)j * an) / N)];
 }
 
+// 1/sqrt(n2) by four Newton steps from an integer seed -- "spec v2", identical operation sequence
+// to rsqrt_nr() in oracle/bpltv_oracle.c (bit-for-bit reproducible; 17 f64 ops instead of the ~31
+// of an IEEE sqrt followed by an IEEE divide).
+__device__ __forceinline__ double rsqrt_nr(double n2) {
+    const unsigned long long u = 0x5FE6EB50C7B537A9ull - ((unsigned long long)__double_as_longlong(n2) >> 1);
+    double r = __longlong_as_double((long long)u);
+    const double h = 0.5 * n2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double t = r * r;
+        const double w = __builtin_fma(-h, t, 1.5);
+        r = r * w;
+    }
+    return r;
+}
+
 template <int PI, int PJ, int TI, int TJ>
 __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     constexpr int RI = PI * TI, RJ = PJ * TJ;
@@ -89,39 +106,72 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     const int tid = threadIdx.x;
     const int ti = tid % TI, tj = tid / TI;
     const int tilesPerImg = A.nTi * A.nTj;
-    const int img = blockIdx.x / tilesPerImg;
-    const int t = blockIdx.x - img * tilesPerImg;
+    const int imgl = blockIdx.x / tilesPerImg;
+    const int img = A.img0 + imgl;
+    const int t = blockIdx.x - imgl * tilesPerImg;
     const int ta = t % A.nTi, tb = t / A.nTi;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
     const int M = A.M, N = A.N;
     const size_t base = (size_t)img * M * N;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const bool first = A.first != 0;
 
+    // ---- prologue: every global load is issued before the first use (one memory round trip).
+    // Out-of-image pixels read a clamped in-image address and are zeroed afterwards.
     double x[PJ][PI], y1[PJ][PI], y2[PJ][PI], f[PJ][PI], al[PJ][PI];
+    size_t gidx[PJ][PI], aidx[PJ][PI];
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
             const int li = ti + TI * pi, lj = tj + TJ * pj;
-            const int gi = oi + li, gj = oj + lj;
-            const bool in = (gi < M) && (gj < N);
-            const size_t idx = base + gi + (size_t)M * gj;
-            double fv = 0.0, xv = 0.0, v1 = 0.0, v2 = 0.0, av = 0.0;
-            if (in) {
-                fv = A.f[idx];
-                av = alpha_at(A.alpha, A.am, A.an, M, N, gi, gj);
-                if (A.first) {
-                    xv = fv;
-                } else {
-                    xv = A.xin[idx];
-                    v1 = A.y1in[idx];
-                    v2 = A.y2in[idx];
-                }
+            const int gi = min(oi + li, M - 1), gj = min(oj + lj, N - 1);
+            gidx[pj][pi] = base + gi + (size_t)M * gj;
+            size_t ai = 0;  // scalar alpha
+            if (amode == 2) {
+                ai = gi + (size_t)M * gj;
+            } else if (amode == 1) {  // PatchOp: piecewise-constant upsampling
+                const unsigned pa = ((unsigned)gi * (unsigned)A.am) / (unsigned)M;
+                const unsigned pb = ((unsigned)gj * (unsigned)A.an) / (unsigned)N;
+                ai = pa + (size_t)A.am * pb;
             }
-            f[pj][pi] = fv; x[pj][pi] = xv; y1[pj][pi] = v1; y2[pj][pi] = v2; al[pj][pi] = av;
-            sy1[lj * RI + li] = v1;
-            sy2[lj * RI + li] = v2;
+            aidx[pj][pi] = ai;
+        }
+    if (!first) {
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+            for (int pi = 0; pi < PI; ++pi) {
+                x[pj][pi] = A.xin[gidx[pj][pi]];
+                y1[pj][pi] = A.y1in[gidx[pj][pi]];
+                y2[pj][pi] = A.y2in[gidx[pj][pi]];
+            }
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+        for (int pi = 0; pi < PI; ++pi) {
+            f[pj][pi] = A.f[gidx[pj][pi]];
+            al[pj][pi] = A.alpha[aidx[pj][pi]];
+        }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+        for (int pi = 0; pi < PI; ++pi) {
+            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const bool in = (oi + li < M) && (oj + lj < N);
+            if (first) {
+                x[pj][pi] = f[pj][pi];
+                y1[pj][pi] = 0.0;
+                y2[pj][pi] = 0.0;
+            }
+            if (!in) {
+                f[pj][pi] = 0.0; x[pj][pi] = 0.0; y1[pj][pi] = 0.0; y2[pj][pi] = 0.0; al[pj][pi] = 0.0;
+            }
+            sy1[lj * RI + li] = y1[pj][pi];
+            sy2[lj * RI + li] = y2[pj][pi];
         }
     __syncthreads();
 
@@ -130,16 +180,27 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * (A.it0 + it);
         const double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
         double xb[PJ][PI];
-        // ---- primal step: x <- prox_{tau*fidelity}(x - tau * G^T y); over-relaxation
+        // ---- primal step: x <- prox_{tau*fidelity}(x - tau * G^T y); over-relaxation.
+        // LDS reads are unconditional (clamped index) and selected afterwards: one wait for all.
+        double y1m[PJ][PI], y2m[PJ][PI];
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const int l = lj * RI + li;
-                const double y1m = (li > 0) ? sy1[l - 1] : 0.0;
-                const double y2m = (lj > 0) ? sy2[l - RI] : 0.0;
-                const double div = (y1m - y1[pj][pi]) + (y2m - y2[pj][pi]);
+                y1m[pj][pi] = sy1[(li > 0) ? l - 1 : l];
+                y2m[pj][pi] = sy2[(lj > 0) ? l - RI : l];
+            }
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+            for (int pi = 0; pi < PI; ++pi) {
+                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                const int l = lj * RI + li;
+                const double a1 = (li > 0) ? y1m[pj][pi] : 0.0;
+                const double a2 = (lj > 0) ? y2m[pj][pi] : 0.0;
+                const double div = (a1 - y1[pj][pi]) + (a2 - y2[pj][pi]);
                 const double tt = div - f[pj][pi];
                 const double xo = x[pj][pi];
                 const double xn = __builtin_fma(-tau, tt, xo) * inv1ptau;
@@ -150,6 +211,16 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             }
         __syncthreads();
         // ---- dual step: y <- proj_{|y_ij| <= alpha_ij}((y + sigma * G xbar) / (1 + sigma*rho/alpha))
+        double xp1[PJ][PI], xpM[PJ][PI];
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+            for (int pi = 0; pi < PI; ++pi) {
+                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                const int l = lj * RI + li;
+                xp1[pj][pi] = sxb[(li < RI - 1) ? l + 1 : l];
+                xpM[pj][pi] = sxb[(lj < RJ - 1) ? l + RI : l];
+            }
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
@@ -158,8 +229,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 const int l = lj * RI + li;
                 const int gi = oi + li, gj = oj + lj;
                 const double b = xb[pj][pi];
-                const double d1 = (li < RI - 1 && gi < M - 1) ? sxb[l + 1] - b : 0.0;
-                const double d2 = (lj < RJ - 1 && gj < N - 1) ? sxb[l + RI] - b : 0.0;
+                const double d1 = (li < RI - 1 && gi < M - 1) ? xp1[pj][pi] - b : 0.0;
+                const double d2 = (lj < RJ - 1 && gj < N - 1) ? xpM[pj][pi] - b : 0.0;
                 const double a = al[pj][pi];
                 double y1n = __builtin_fma(sigma, d1, y1[pj][pi]);
                 double y2n = __builtin_fma(sigma, d2, y2[pj][pi]);
@@ -170,7 +241,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 }
                 const double n2 = __builtin_fma(y2n, y2n, y1n * y1n);
                 if (n2 > a * a) {
-                    const double v = a / sqrt(n2);
+                    const double v = a * rsqrt_nr(n2);
                     y1n = y1n * v;
                     y2n = y2n * v;
                 }

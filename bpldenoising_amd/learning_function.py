@@ -89,6 +89,7 @@ class TVSolver:
         p = _lib.BpltvParams()
         self._lib.bpltv_default_params(C.byref(p))
         variant = kw.pop("variant", None)
+        chains = kw.pop("chains", None)
         for k, v in kw.items():
             if k in _IGNORED:
                 continue
@@ -98,7 +99,9 @@ class TVSolver:
             cur = getattr(p, f)
             setattr(p, f, type(cur)(v))
         if variant is not None:
-            p.reserved[0] = int(variant)
+            p.reserved[0] = int(variant)   # PDHG kernel variant (1-based), 0 = auto
+        if chains is not None:
+            p.reserved[1] = int(chains)    # independent launch chains in the hipGraph, 0 = auto
         return p
 
     def _batch(self, a, what):

@@ -6,7 +6,7 @@
  *
  * PARITY UNPINNED BY THE REFERENCE.  The reference is Julia; its PDHG loop (`op_denoise_pdps`)
  * lives in the un-vendored, un-pinned package VariationalImaging and its tests hold no expected
- * values.  This file therefore *defines* the arithmetic ("spec v1") that the HIP
+ * values.  This file therefore *defines* the arithmetic ("spec v2") that the HIP
  * kernels reproduce bit for bit, and is itself pinned by
  *   - oracle/np_twin.py (numpy restatement of the same recurrence; literal scipy assembly of the
  *     reference's adjoint systems) through tests/golden fixtures,
@@ -21,6 +21,7 @@
  * fma(), so that CPU and GPU round identically).
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
@@ -107,7 +108,7 @@ BPLO_API void bplo_grad_fwd_T(int M, int N, const double *y1, const double *y2, 
 }
 
 /* ------------------------------------------------------------------------------------------
- * Accelerated PDHG for ROF, fixed iteration count (A2, A3, A9).  "spec v1" arithmetic:
+ * Accelerated PDHG for ROF, fixed iteration count (A2, A3, A9).  "spec v2" arithmetic:
  *
  *   x-step  div = (y1[i-1,j] - y1[i,j]) + (y2[i,j-1] - y2[i,j])        (out of range -> 0)
  *           xn  = fma(-tau, div - f, x) * inv1ptau
@@ -115,10 +116,32 @@ BPLO_API void bplo_grad_fwd_T(int M, int N, const double *y1, const double *y2, 
  *   y-step  d1  = xb[i+1,j] - xb[i,j]  (0 at i = M-1),  d2 likewise in j
  *           y1n = fma(sigma, d1, y1),  y2n = fma(sigma, d2, y2)
  *           rho != 0:  y?n /= (1 + sigma*rho/alpha_ij)
- *           n2  = fma(y2n, y2n, y1n*y1n);  if n2 > alpha_ij^2:  v = alpha_ij / sqrt(n2); y?n *= v
+ *           n2  = fma(y2n, y2n, y1n*y1n);  if n2 > alpha_ij^2:  v = alpha_ij * rsqrt_nr(n2); y?n *= v
+ *
+ * rsqrt_nr (below) is 1/sqrt by four Newton steps from an integer-seeded guess: a fixed sequence of
+ * IEEE multiplies and fmas, so CPU and GPU agree bit for bit while the GPU avoids the ~30-instruction
+ * correctly-rounded sqrt + divide pair.  It differs from alpha/sqrt(n2) by <= 3 ulp (the projected
+ * dual has |y| = alpha(1 +- 4e-16)).  Domain: n2 in the normal range, i.e. alpha > ~1e-150.
  *
  * x starts at f, y at 0.  Outputs: x (primal), optionally y1, y2.
  * ---------------------------------------------------------------------------------------- */
+static inline double rsqrt_nr(double n2)
+{
+    union { double d; uint64_t u; } c;
+    c.d = n2;
+    c.u = 0x5FE6EB50C7B537A9ull - (c.u >> 1); /* relative error of the seed < 3.5e-2 */
+    double r = c.d;
+    const double h = 0.5 * n2;
+    for (int k = 0; k < 4; ++k) { /* e -> 1.5 e^2: 1.8e-3, 4.6e-6, 3.2e-11, 1.5e-21 */
+        double t = r * r;
+        double w = fma(-h, t, 1.5);
+        r = r * w;
+    }
+    return r;
+}
+
+BPLO_API double bplo_rsqrt_nr(double n2) { return rsqrt_nr(n2); }
+
 static void pdhg_image(int M, int N, const double *f, const double *alpha, int am, int an,
                        const double *tab, int maxiter, double rho, double *x, double *y1, double *y2,
                        double *xb)
@@ -157,7 +180,7 @@ static void pdhg_image(int M, int N, const double *f, const double *alpha, int a
                 }
                 double n2 = fma(y2n, y2n, y1n * y1n);
                 if (n2 > a * a) {
-                    double v = a / sqrt(n2);
+                    double v = a * rsqrt_nr(n2);
                     y1n = y1n * v;
                     y2n = y2n * v;
                 }

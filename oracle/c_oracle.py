@@ -47,6 +47,8 @@ def lib():
                                     C.c_double, C.c_int, _dp, _dp]
         L.bplo_gradient.restype = C.c_int
         L.bplo_max_threads.restype = C.c_int
+        L.bplo_rsqrt_nr.argtypes = [C.c_double]
+        L.bplo_rsqrt_nr.restype = C.c_double
         _lib = L
     return _lib
 
@@ -141,7 +143,7 @@ def patch_adjoint(g, am, an):
     return out
 
 
-def gradient_image(u, ubar, amap, patch=False, reg=False, kappa_cap=1e12, nref=2):
+def gradient_image(u, ubar, amap, patch=False, reg=False, kappa_cap=1e14, nref=3):
     u = _c(u); ubar = _c(ubar); amap = _c(amap)
     N, M = u.shape
     gpix = np.empty_like(u); p = np.empty_like(u)
@@ -153,7 +155,7 @@ def gradient_image(u, ubar, amap, patch=False, reg=False, kappa_cap=1e12, nref=2
     return gpix, p, res.value
 
 
-def gradient(alpha, u, ubar, reg=False, kappa_cap=1e12, nref=2, per_image=False):
+def gradient(alpha, u, ubar, reg=False, kappa_cap=1e14, nref=3, per_image=False):
     u = _c(u); ubar = _c(ubar)
     O, N, M = u.shape
     a, am, an = alpha_arg(alpha)
@@ -174,6 +176,10 @@ def tv_op_learning_function(x, data, delta, delta_t=1e-6, maxiter=5000, rho=0.0,
     c = cost(u, ubar)
     g = gradient(x, u, ubar, reg=not (delta > delta_t))
     return u, c, g
+
+
+def rsqrt_nr(x):
+    return lib().bplo_rsqrt_nr(float(x))
 
 
 def max_threads():

@@ -102,6 +102,17 @@ def step_table(maxiter, tau0=5.0, sigma0=0.99 / 5, accel=True):
     return tab
 
 
+def rsqrt_nr(n2):
+    """1/sqrt by four Newton steps from an integer seed ("spec v2", oracle/bpltv_oracle.c); numpy
+    has no fma, so this agrees with the C oracle to a few ulp, not bit for bit."""
+    n2 = np.ascontiguousarray(n2, dtype=np.float64)
+    r = (np.uint64(0x5FE6EB50C7B537A9) - (n2.view(np.uint64) >> np.uint64(1))).view(np.float64)
+    h = 0.5 * n2
+    for _ in range(4):
+        r = r * (1.5 - h * (r * r))
+    return r
+
+
 def pdhg_denoise(f, alpha, maxiter=5000, tau0=5.0, sigma0=0.99 / 5, accel=True, rho=0.0,
                  return_dual=False):
     """ROF denoising of a batch by accelerated PDHG, fixed iteration count.
@@ -110,6 +121,7 @@ def pdhg_denoise(f, alpha, maxiter=5000, tau0=5.0, sigma0=0.99 / 5, accel=True, 
     batch.  Restates SURVEY.md 8(a) A2:  x=f, y=0; per iteration
         x_old=x; x=(x - tau*(G^T y - f))/(1+tau); xb=(1+omega)x - omega*x_old;
         y=(y + sigma*G xb)/(1 + sigma*rho/alpha); y <- proj_{|y_ij|<=alpha_ij}; tau*=omega; sigma/=omega
+    (projection factor alpha*rsqrt_nr(|y|^2), see rsqrt_nr)
     """
     f = np.asarray(f, dtype=np.float64)
     N, M = f.shape[-2:]
@@ -133,8 +145,8 @@ def pdhg_denoise(f, alpha, maxiter=5000, tau0=5.0, sigma0=0.99 / 5, accel=True, 
             y1 = y1 / den
             y2 = y2 / den
         n2 = y1 * y1 + y2 * y2
-        with np.errstate(divide="ignore", invalid="ignore"):
-            v = np.where(n2 > a2, amap / np.sqrt(n2), 1.0)
+        with np.errstate(all="ignore"):
+            v = np.where(n2 > a2, amap * rsqrt_nr(np.where(n2 > a2, n2, 1.0)), 1.0)
         y1 = y1 * v
         y2 = y2 * v
     if return_dual:

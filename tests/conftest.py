@@ -1,0 +1,67 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATASETS_NPZ = os.path.join(GOLDEN, "datasets.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def datasets_npz():
+    return DATASETS_NPZ
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    z = np.load(os.path.join(GOLDEN, "golden_v2.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, {m["name"]: m for m in meta}
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import c_oracle
+    c_oracle.build()
+    return c_oracle
+
+
+def synth_batch(O, N, M, seed=1, sigma=0.1):
+    """Piecewise-smooth truth + quantised Gaussian noise (same recipe as bench.py)."""
+    rng = np.random.default_rng(seed)
+    jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+    ub = np.zeros((O, N, M))
+    for k in range(O):
+        img = 0.3 + 0.4 * (ii / max(M, 1)) * rng.random() + 0.2 * (jj / max(N, 1)) * rng.random()
+        for _ in range(5):
+            ci, cj, r = rng.random() * M, rng.random() * N, (0.05 + 0.2 * rng.random()) * min(M, N)
+            img = np.where((ii - ci) ** 2 + (jj - cj) ** 2 < r * r, rng.random(), img)
+        ub[k] = np.clip(img, 0, 1)
+    f = np.round(255 * np.clip(ub + sigma * rng.standard_normal(ub.shape), 0, 1)) / 255
+    return ub, f
+
+
+@pytest.fixture(scope="session")
+def gpu_solver_cls():
+    """The HIP TVSolver class.  Skips only when no GPU is visible; a missing or unloadable
+    libbpltv.so is an error (the product path must fail loudly, not fall back)."""
+    from bpldenoising_amd import TVSolver, _lib
+    lib = _lib.load()  # raises if the library is absent
+    import ctypes as C
+    h = C.c_void_p()
+    rc = lib.bpltv_create(C.byref(h), 8, 8, 1, -1, 64)
+    if rc != 0:
+        if h:
+            lib.bpltv_destroy(h)
+        pytest.skip("no HIP device visible (bpltv_create rc=%d)" % rc)
+    lib.bpltv_destroy(h)
+    return TVSolver

@@ -1,0 +1,65 @@
+"""Oracle PDHG: C restatement vs numpy twin, closed-form cases, duality-gap certificate
+(SURVEY.md 8c (i), (iii))."""
+import numpy as np
+import pytest
+from oracle import np_twin as T
+from conftest import synth_batch
+
+
+@pytest.mark.parametrize("alpha", [0.1, np.array([[0.05, 0.1], [0.2, 0.08]]), "map"])
+def test_c_matches_numpy_twin(oracle, alpha):
+    ub, f = synth_batch(2, 30, 22, seed=5)
+    if isinstance(alpha, str):
+        alpha = 0.05 + 0.1 * np.random.default_rng(0).random((30, 22))
+    u = oracle.pdhg(f, alpha, maxiter=400)
+    ut = T.pdhg_denoise(f, alpha, maxiter=400)
+    assert np.abs(u - ut).max() < 1e-12
+
+
+def test_rho_and_no_accel(oracle):
+    ub, f = synth_batch(1, 20, 20, seed=6)
+    u = oracle.pdhg(f, 0.1, maxiter=300, rho=0.05, accel=False)
+    ut = T.pdhg_denoise(f, 0.1, maxiter=300, rho=0.05, accel=False)
+    assert np.abs(u - ut).max() < 1e-12
+
+
+def test_closed_form_cases(oracle):
+    ub, f = synth_batch(1, 16, 16, seed=7)
+    assert np.abs(oracle.pdhg(f, 0.0, maxiter=50) - f).max() < 1e-15   # alpha = 0 => u = f (to rounding)
+    c = np.full((1, 16, 16), 0.37)
+    assert np.abs(oracle.pdhg(c, 0.2, maxiter=200) - c).max() < 1e-15  # constant f => u = f
+    u = oracle.pdhg(f, 50.0, maxiter=4000)                             # alpha >= alpha_max => mean(f)
+    assert np.abs(u - f.mean()).max() < 1e-6
+    assert np.array_equal(oracle.pdhg(f, 0.1, maxiter=0), f)           # maxiter = 0
+
+
+def test_transposition_equivariance(oracle):
+    ub, f = synth_batch(1, 24, 18, seed=8)
+    u = oracle.pdhg(f, 0.1, maxiter=300)
+    ut = oracle.pdhg(np.ascontiguousarray(f.transpose(0, 2, 1)), 0.1, maxiter=300)
+    assert np.abs(u - ut.transpose(0, 2, 1)).max() < 1e-12
+
+
+def test_gap_certificate(oracle):
+    ub, f = synth_batch(1, 32, 32, seed=9)
+    alpha = 0.1
+    ustar = oracle.pdhg(f, alpha, maxiter=40000)
+    prev = None
+    for it in (50, 200, 1000, 5000):
+        u, y1, y2 = oracle.pdhg(f, alpha, maxiter=it, return_dual=True)
+        assert np.max(np.sqrt(y1 ** 2 + y2 ** 2)) <= alpha * (1 + 1e-15)     # dual feasible
+        gap = oracle.gap(u, y1, y2, f, alpha)[0]
+        assert gap >= -1e-12
+        assert 0.5 * np.sum((u - ustar) ** 2) <= gap + 1e-9                # strong convexity bound
+        assert np.isclose(gap, T.rof_gap(u, y1, y2, f, alpha)[0], rtol=1e-6, atol=1e-12)
+        if prev is not None:
+            assert gap < prev
+        prev = gap
+    assert prev < 1e-5
+
+
+def test_cost(oracle):
+    ub, f = synth_batch(3, 10, 12, seed=10)
+    tot, per = oracle.cost(f, ub, per_image=True)
+    assert np.isclose(tot, T.l2_cost(f, ub), rtol=1e-14)
+    assert np.isclose(per.sum(), tot, rtol=1e-15)
