@@ -87,6 +87,16 @@ def load():
             "bpldenoising_amd: %s is missing -- the HIP library has not been built "
             "(run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root). "
             "There is no CPU fallback." % LIB_PATH)
+    # Coexistence with PyTorch-ROCm in one process: torch ships its own libamdhip64/libhsa-runtime.
+    # Whichever HIP runtime is loaded first serves both (same SONAME); two initialised runtimes in
+    # one process leave the second without GPUs.  So when torch is installed, let it load first.
+    if os.environ.get("BPLTV_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
