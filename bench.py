@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chains", type=int, default=0, help="independent launch chains (0 = library default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU rehearsal)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0 = auto)")
     args = ap.parse_args()
 
@@ -78,10 +81,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from bpldenoising_amd import TVSolver, shard_range
 
@@ -104,6 +112,9 @@ def main():
     kw = dict(maxiter=args.iters, tile_iters=args.tile_iters, use_graph=0 if args.no_graph else 1)
     if args.variant:
         kw["variant"] = args.variant
+    if args.chains:
+        kw["chains"] = args.chains
+    gloo = world > 1 and args.backend != "nccl"
     if O_local > 0:
         solver = TVSolver(M, N, O_local, device=local_rank)
         t_ub = torch.from_numpy(ub).cuda()
@@ -118,7 +129,10 @@ def main():
             if solver is not None:
                 solver.evaluate_device(alpha, 0.1, part.data_ptr(), **kw)
             if world > 1:
-                dist.all_reduce(part)
+                if gloo:
+                    pc = part.cpu(); dist.all_reduce(pc); part.copy_(pc)
+                else:
+                    dist.all_reduce(part)
         elif solver is not None:
             solver.denoise(alpha, fetch=False, **kw)
 
@@ -141,7 +155,7 @@ def main():
             ev_launches += st["launches"]
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     T = float(tmax.item())
@@ -152,6 +166,14 @@ def main():
         value = batches * args.steps * args.iters / T
         bytes_px = st["bytes_per_px_iter"]
         launch_us = 1e3 * ev_ms / max(ev_launches, 1)
+        # isolated duration of one launch (chains replayed one after the other), the number a
+        # rocprofv3 --kernel-trace of this command reports per kernel
+        ser_ms, ser_l = 0.0, 0
+        if not args.evaluate:
+            for _ in range(3):
+                solver.denoise(alpha, fetch=False, serialize_chains=1, **kw)
+                s2 = solver.stats(); ser_ms += s2["pdhg_ms"]; ser_l += s2["launches"]
+        kernel_us = 1e3 * ser_ms / max(ser_l, 1) if ser_l else None
         bytes_per_launch = bytes_px * M * N * O_local * (args.iters / max(st["launches"], 1))
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
         traffic = None
@@ -181,6 +203,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "pdhg_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
+                         "avg_kernel_us_serialized": kernel_us,
+                         "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
+                         "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
                          "bytes_per_px_iter": bytes_px},
             "pdhg_event_ms_per_step": ev_ms / args.steps,
         }

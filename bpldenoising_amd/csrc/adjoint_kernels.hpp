@@ -128,128 +128,325 @@ __device__ __forceinline__ double band_init(const double* __restrict__ band4, si
     return v;
 }
 
-// Banded Cholesky A = L L^T, bandwidth bw = M, one workgroup (1024 threads) per image.
-// LDS: ring of W = M+1 columns x W rows (the trailing window) + the current column.
+// Broadcast of lane `src` (wave-uniform, a constant after unrolling) through SGPRs: v_readlane_b32,
+// a few cycles -- not ds_bpermute, whose ~100-cycle latency would sit in the substitution chain.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt and 1/sqrt of a positive pivot from v_rsq_f64 + Newton (the adjoint solve is refined
+// iteratively and compared with a tolerance, so no correctly-rounded sqrt/divide chain is needed
+// in the sequential part of the factorisation).
+__device__ __forceinline__ void sqrt_rsqrt(double a, double& s, double& r) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * __builtin_fma(-h, y * y, 1.5);
+    y = y * __builtin_fma(-h, y * y, 1.5);
+    double g = a * y;
+    g = __builtin_fma(0.5 * y, __builtin_fma(-g, g, a), g);
+    s = g;
+    r = y;
+}
+
+// Banded Cholesky A = L L^T, bandwidth bw = M, one workgroup (ADJ_FT threads) per image, blocked by
+// panels of NB columns.
+//   LDS: ring of RS = bw+NB column slots x W = bw+1 rows (the trailing window; 141 KB for M = 128,
+//        NB = 8), the current panel lp[NB][bw+NB] and the NB x NB diagonal factor.
+//   per panel: (1) every thread redundantly factors the NB x NB diagonal block (no barrier),
+//   (2) one thread per row forward-substitutes its NB panel entries, stores them to LDS and to L,
+//   (3) barrier; the bw(bw+1)/2 trailing elements -- a fixed, balanced list of (column, offset)
+//   pairs per thread, decoded once -- each subtract an NB-term dot product of panel rows; the NB
+//   consumed slots are re-initialised with the next columns of A; barrier.
 // L is written to global memory as [O][n][W] (column k: L[k+d][k] at d).
-__global__ __launch_bounds__(1024) void adj_factor_kernel(const double* __restrict__ band4, int M,
-                                                          int N, int O, double* __restrict__ L,
+constexpr int ADJ_FT = 512;         // threads of the factorisation workgroup (256 VGPRs each)
+
+template <int NB, int MC>  // MC: compile-time M (0 = run-time)
+__global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __restrict__ band4, int Mrt, int N,
+                                                          int O, double* __restrict__ L,
                                                           int* __restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int W = M + 1, bw = M;
-    double* win = smem;          // [W][W]
-    double* lv = smem + W * W;   // [W]
+    const int M = MC ? MC : Mrt;
+    const int bw = M, W = M + 1, RS = bw + NB, PR = bw + NB;  // ring slots, panel rows
+    double* win = smem;                // [RS][W]
+    double* lp = smem + RS * W;        // [NB][PR]
     const int img = blockIdx.x;
     const int n = M * N;
     const size_t tot = (size_t)n * O;
     const size_t ib = (size_t)img * n;
     const int tid = threadIdx.x;
-    for (int e = tid; e < W * W; e += 1024) {
+
+    for (int e = tid; e < RS * W; e += ADJ_FT) {
         const int c = e / W, d = e - c * W;
-        win[e] = (c < n) ? band_init(band4, tot, ib + c, d, M) : 0.0;
+        win[e] = (c < n) ? band_init(band4, tot, ib + c, d, M) : (d == 0 ? 1.0 : 0.0);
     }
+    // trailing elements of a panel step: window column t (0..bw-1, i.e. panel-relative column NB+t)
+    // holds bw - t elements (row offsets o = 0 .. bw-t-1); linear index -> (t, o), decoded once.
+    // The bw(bw+1)/2 trailing elements as a rectangle: row p pairs window column p (bw-p elements)
+    // with column bw-1-p (p+1 elements) -> bw+1 = W entries per row, HR = ceil(bw/2) rows (for odd
+    // bw the middle column stands alone).  Linear index e = p*W + q walks it with stride ADJ_FT.
+    const int HR = (bw + 1) / 2;
+    const int NEr = HR * W;
+    const int dp = ADJ_FT / W, dq = ADJ_FT - dp * W;
+    const int p0 = tid / W, q0 = tid - p0 * W;
     __syncthreads();
-    const int g = tid >> 7, qq = tid & 127;
-    for (int k = 0; k < n; ++k) {
-        const int s = k % W;
-        const int lim = (n - 1 - k < bw) ? (n - 1 - k) : bw;
-        const double piv = win[s * W];
-        if (!(piv > 0.0)) {
-            if (tid == 0) fail[img] = k + 1;
-            return;  // uniform: every thread reads the same pivot
+
+    int slot0 = 0;  // ring slot of column k
+    for (int k = 0; k < n; k += NB) {
+        // ---- (1) diagonal block, redundantly in every thread of the row waves (no barrier needed):
+        //          m = chol(A[k..k+NB, k..k+NB]).  The other waves go straight to the barrier.
+        double m[NB][NB], dinv[NB];
+        const bool rowwave = (tid & ~63) < PR;  // wave holds at least one panel row
+        if (rowwave) {
+            bool bad = false;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                int sb = slot0 + b; if (sb >= RS) sb -= RS;
+#pragma unroll
+                for (int a = b; a < NB; ++a) m[a][b] = win[sb * W + (a - b)];
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                double piv = m[c][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) piv -= m[c][q] * m[c][q];
+                if (!(piv > 0.0)) bad = true;
+                double d, di;
+                sqrt_rsqrt(piv, d, di);
+                m[c][c] = d;
+                dinv[c] = di;
+#pragma unroll
+                for (int a = c + 1; a < NB; ++a) {
+                    double v = m[a][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= m[a][q] * m[c][q];
+                    m[a][c] = v * dinv[c];
+                }
+            }
+            if (bad && tid == 0) fail[img] = k + 1;  // factor continues with NaNs; host reports the failure
         }
-        const double d = sqrt(piv);
-        const double inv = 1.0 / d;
-        for (int r = tid; r <= bw; r += 1024) {
-            double v = 0.0;
-            if (r == 0) v = d;
-            else if (r <= lim) v = win[s * W + r] * inv;
-            lv[r] = v;
-            L[(ib + k) * W + r] = v;
+        // ---- (2) panel rows
+        if (rowwave && tid < PR) {
+            const int rr = tid;
+            double l[NB];
+            if (rr < NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int a = 0; a < NB; ++a)
+                        if (a == rr && c <= a) v = m[a][c];
+                    l[c] = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    int sc = slot0 + c; if (sc >= RS) sc -= RS;
+                    double v = (rr - c <= bw) ? win[sc * W + (rr - c)] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= l[q] * m[c][q];
+                    l[c] = v * dinv[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                lp[c * PR + rr] = l[c];
+                const int d = rr - c;
+                if (d >= 0 && d <= bw && k + c < n) L[(ib + k + c) * W + d] = (k + rr < n) ? l[c] : 0.0;
+            }
         }
         __syncthreads();
-        // recycle slot s for column k + W
-        for (int r = tid; r <= bw; r += 1024)
-            win[s * W + r] = (k + W < n) ? band_init(band4, tot, ib + k + W, r, M) : 0.0;
-        // trailing update: win[col k+c][r-c] -= l_r * l_c, 1 <= c <= r <= lim
-        for (int c = 1 + g; c <= lim; c += 8) {
-            const double lc = lv[c];
-            double* col = win + ((k + c) % W) * W;
-            for (int o = qq; c + o <= lim; o += 128) col[o] -= lv[c + o] * lc;
+        // ---- (3a) recycle the NB consumed slots for columns k+RS .. k+RS+NB-1
+        for (int e = tid; e < NB * W; e += ADJ_FT) {
+            const int q = e / W, d = e - q * W;
+            int sq = slot0 + q; if (sq >= RS) sq -= RS;
+            const int col = k + RS + q;
+            win[sq * W + d] = (col < n) ? band_init(band4, tot, ib + col, d, M) : (d == 0 ? 1.0 : 0.0);
+        }
+        // ---- (3b) trailing update: A[j+o][j] -= sum_c lp[c][row] * lp[c][col]
+        {
+            int p = p0, q = q0;
+            for (int e = tid; e < NEr; e += ADJ_FT) {
+                const bool first = q < bw - p;
+                const int t = first ? p : bw - 1 - p;
+                const int o = first ? q : q - (bw - p);
+                if (first || 2 * p != bw - 1) {  // odd bw: the middle column is not paired with itself
+                    const int jr = NB + t, rrow = jr + o;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) acc = __builtin_fma(lp[c * PR + rrow], lp[c * PR + jr], acc);
+                    int sj = slot0 + jr; if (sj >= RS) sj -= RS;
+                    win[sj * W + o] -= acc;
+                }
+                p += dp; q += dq;
+                if (q >= W) { q -= W; ++p; }
+            }
         }
         __syncthreads();
+        slot0 += NB; if (slot0 >= RS) slot0 -= RS;
     }
-    if (tid == 0) fail[img] = 0;
 }
 
-// Solve L L^T x = b in place (x: [O][n]), blocked by 64 columns; one workgroup of 256 per image.
-// If `acc` is non-null the result is added to acc (p += dp) instead of being left in x.
-__global__ __launch_bounds__(256) void adj_solve_kernel(const double* __restrict__ L, int M, int N,
+// Inverses of the 64x64 diagonal blocks of L, so that the block substitutions of the solve become
+// matrix-vector products without a 64-step dependent chain.  One wave per block: lane j builds
+// column j of inv(L_bb) by forward substitution (L_bb staged in LDS).  Output, per image and block,
+// two layouts of the same lower-triangular matrix X = inv(L_bb):
+//   invF[(c*64 + r)] = X[r][c]  (lane r reads row r, coalesced over r)     -> forward  y = X b
+//   invB[(r*64 + c)] = X[r][c]  (lane c reads column c, coalesced over c)  -> backward x = X^T z
+// Rows/columns beyond n are padded with the identity.
+constexpr int SB = 64;
+__global__ __launch_bounds__(64) void adj_invdiag_kernel(const double* __restrict__ L, int M, int N,
+                                                         double* __restrict__ invF, double* __restrict__ invB) {
+    __shared__ double tri[SB * (SB + 1)];  // L_bb element (r, c) at r*65 + c
+    __shared__ double X[SB * (SB + 1)];    // X element (r, j) at r*65 + j
+    const int W = M + 1, bw = M, n = M * N;
+    const int nblk = (n + SB - 1) / SB;
+    const int bi = blockIdx.x, img = blockIdx.y;
+    const int k0 = bi * SB, lane = threadIdx.x;
+    const double* Li = L + (size_t)img * n * W;
+    for (int c = 0; c < SB; ++c) {  // column c of the block: rows r = lane, coalesced
+        const int r = lane;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r >= c && k0 + r < n && k0 + c < n && r - c <= bw) v = Li[(size_t)(k0 + c) * W + (r - c)];
+        tri[r * (SB + 1) + c] = v;
+    }
+    __syncthreads();
+    const int j = lane;
+    for (int r = 0; r < SB; ++r) {
+        double v = 0.0;
+        if (r == j) {
+            v = 1.0 / tri[r * (SB + 1) + r];
+        } else if (r > j) {
+            double sacc = 0.0;
+            for (int c = j; c < r; ++c) sacc = __builtin_fma(tri[r * (SB + 1) + c], X[c * (SB + 1) + j], sacc);
+            v = -sacc / tri[r * (SB + 1) + r];
+        }
+        X[r * (SB + 1) + j] = v;  // lane j only touches column j: no barrier needed
+    }
+    __syncthreads();
+    const size_t ob = ((size_t)img * nblk + bi) * SB * SB;
+    for (int q = 0; q < SB; ++q) {
+        invF[ob + (size_t)q * SB + lane] = X[lane * (SB + 1) + q];  // c = q, r = lane
+        invB[ob + (size_t)q * SB + lane] = X[q * (SB + 1) + lane];  // r = q, c = lane
+    }
+}
+
+// Solve L L^T x = b in place (x: [O][n]), blocks of 64 columns, one workgroup of 256 per image.
+// The running right-hand side lives in an LDS ring of 256 rows; per block, wave 0 applies the
+// inverted diagonal block (64 fmas per lane, operands broadcast by v_readlane), the other waves
+// have already prefetched their rows of L and apply the rank-64 update to the following bw rows
+// (forward) / the tail dot products with already solved entries (backward).
+// If `acc` is non-null the solution is also added to acc (p += dp).
+constexpr int RING = 256;
+__global__ __launch_bounds__(256) void adj_solve_kernel(const double* __restrict__ L,
+                                                        const double* __restrict__ invF,
+                                                        const double* __restrict__ invB, int M, int N,
                                                         double* __restrict__ x,
                                                         double* __restrict__ acc) {
-    constexpr int B = 64;
-    __shared__ double xs[B];
-    __shared__ double ps[B][4];
+    __shared__ double ring[RING];
+    __shared__ double xs[SB];
+    __shared__ double ps[SB][4];
     const int W = M + 1, bw = M;
     const int n = M * N;
     const size_t ib = (size_t)blockIdx.x * n;
     const double* Li = L + ib * W;
     double* xv = x + ib;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = (n + SB - 1) / SB;
+    const double* iF = invF + (size_t)blockIdx.x * nblk * SB * SB;
+    const double* iB = invB + (size_t)blockIdx.x * nblk * SB * SB;
 
-    // ---- forward: L y = b
-    for (int k0 = 0; k0 < n; k0 += B) {
-        const int nb = (n - k0 < B) ? (n - k0) : B;
+    // ---------------- forward: L y = b.  ring[r & 255] holds the current b[r] for r in [k0, k0+256)
+    ring[tid] = (tid < n) ? xv[tid] : 0.0;
+    __syncthreads();
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int k0 = bi * SB;
+        const int rend = (k0 + SB - 1 + bw < n - 1) ? (k0 + SB - 1 + bw) : (n - 1);
+        double pre[SB];
+        const int urow = k0 + SB + (tid - 64);  // rows beyond the block, one per thread of waves 1..3
         if (wv == 0) {
-            double val = (lane < nb) ? xv[k0 + lane] : 0.0;
-            for (int c = 0; c < nb; ++c) {
-                const double dc = Li[(size_t)(k0 + c) * W];
-                const double v = __shfl(val, c, 64) / dc;
-                if (lane == c) val = v;
-                if (lane > c && lane < nb && lane - c <= bw) val -= Li[(size_t)(k0 + c) * W + (lane - c)] * v;
+            double xr[SB];
+            const double* blk = iF + (size_t)bi * SB * SB;
+#pragma unroll
+            for (int c = 0; c < SB; ++c) xr[c] = blk[c * SB + lane];  // X[lane][c]
+            const double bv = ring[(k0 + lane) & (RING - 1)];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int c = 0; c < SB; c += 4) {
+                a0 = __builtin_fma(xr[c], readlane_f64(bv, c), a0);
+                a1 = __builtin_fma(xr[c + 1], readlane_f64(bv, c + 1), a1);
+                a2 = __builtin_fma(xr[c + 2], readlane_f64(bv, c + 2), a2);
+                a3 = __builtin_fma(xr[c + 3], readlane_f64(bv, c + 3), a3);
             }
-            if (lane < nb) { xs[lane] = val; xv[k0 + lane] = val; }
+            const double val = (a0 + a1) + (a2 + a3);
+            xs[lane] = val;
+            if (k0 + lane < n) xv[k0 + lane] = val;
+        } else {
+#pragma unroll
+            for (int c = 0; c < SB; ++c) {
+                const int d = urow - (k0 + c);
+                pre[c] = (urow <= rend && d <= bw) ? Li[(size_t)(k0 + c) * W + d] : 0.0;
+            }
         }
         __syncthreads();
-        // rows beyond the block: r in [k0+nb, k0+nb-1+bw]
-        const int rend = (k0 + nb - 1 + bw < n - 1) ? (k0 + nb - 1 + bw) : (n - 1);
-        for (int r = k0 + nb + tid; r <= rend; r += 256) {
-            double sacc = 0.0;
-            for (int c = 0; c < nb; ++c) {
-                const int d = r - (k0 + c);
-                if (d <= bw) sacc += Li[(size_t)(k0 + c) * W + d] * xs[c];
+        if (wv == 0) {  // refill the 64 ring slots that just left the window
+            const int rnew = k0 + RING + lane;
+            ring[(k0 + lane) & (RING - 1)] = (rnew < n) ? xv[rnew] : 0.0;
+        } else if (urow <= rend) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < SB; c += 2) {
+                s0 = __builtin_fma(pre[c], xs[c], s0);
+                s1 = __builtin_fma(pre[c + 1], xs[c + 1], s1);
             }
-            xv[r] -= sacc;
+            ring[urow & (RING - 1)] -= s0 + s1;
         }
         __syncthreads();
     }
-    // ---- backward: L^T x = y
-    const int nblk = (n + B - 1) / B;
+    // ---------------- backward: L^T x = y.  ring[r & 255] holds solved x[r] for r in [k0+64, k0+256)
     for (int bi = nblk - 1; bi >= 0; --bi) {
-        const int k0 = bi * B;
-        const int nb = (n - k0 < B) ? (n - k0) : B;
-        // contributions of already-solved entries beyond the block: column c, rows k0+nb .. k0+c+bw
-        {
-            const int c = tid >> 2, part = tid & 3;  // 64 columns x 4 partial sums
+        const int k0 = bi * SB;
+        const int nb = (n - k0 < SB) ? (n - k0) : SB;
+        double xc[SB];
+        if (wv == 0) {
+            const double* blk = iB + (size_t)bi * SB * SB;
+#pragma unroll
+            for (int r = 0; r < SB; ++r) xc[r] = blk[r * SB + lane];  // X[r][lane]
+        }
+        {   // tails: column c, rows beyond the block (already solved, in the ring)
+            const int c = tid >> 2, part = tid & 3;
             double sacc = 0.0;
             if (c < nb) {
                 const int kc = k0 + c;
-                const int dlo = k0 + nb - kc;  // first offset beyond the block (>= 1)
+                const int dlo = k0 + nb - kc;
                 const int dhi = (n - 1 - kc < bw) ? (n - 1 - kc) : bw;
-                for (int d = dlo + part; d <= dhi; d += 4) sacc += Li[(size_t)kc * W + d] * xv[kc + d];
+                double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int d0 = dlo + part; d0 <= dhi; d0 += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int d = d0 + 4 * u;
+                        if (d <= dhi) a8[u] = __builtin_fma(Li[(size_t)kc * W + d], ring[(kc + d) & (RING - 1)], a8[u]);
+                    }
+                }
+                sacc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             }
             ps[c][part] = sacc;
         }
         __syncthreads();
         if (wv == 0) {
-            double val = 0.0;
-            if (lane < nb) val = xv[k0 + lane] - (((ps[lane][0] + ps[lane][1]) + ps[lane][2]) + ps[lane][3]);
-            for (int c = nb - 1; c >= 0; --c) {
-                const double dc = Li[(size_t)(k0 + c) * W];
-                const double v = __shfl(val, c, 64) / dc;
-                if (lane == c) val = v;
-                // x_lane (lane < c) loses L[k0+c][k0+lane] * x_c = column (k0+lane), offset c-lane
-                if (lane < c && c - lane <= bw) val -= Li[(size_t)(k0 + lane) * W + (c - lane)] * v;
+            double zv = 0.0;
+            if (lane < nb) zv = xv[k0 + lane] - (((ps[lane][0] + ps[lane][1]) + ps[lane][2]) + ps[lane][3]);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int r = 0; r < SB; r += 4) {
+                a0 = __builtin_fma(xc[r], readlane_f64(zv, r), a0);
+                a1 = __builtin_fma(xc[r + 1], readlane_f64(zv, r + 1), a1);
+                a2 = __builtin_fma(xc[r + 2], readlane_f64(zv, r + 2), a2);
+                a3 = __builtin_fma(xc[r + 3], readlane_f64(zv, r + 3), a3);
             }
+            const double val = (a0 + a1) + (a2 + a3);
+            ring[(k0 + lane) & (RING - 1)] = val;
             if (lane < nb) {
                 if (acc) acc[ib + k0 + lane] += val;
                 xv[k0 + lane] = val;

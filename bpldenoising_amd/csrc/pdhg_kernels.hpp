@@ -40,6 +40,7 @@ struct PdhgArgs {
     int nTi, nTj, halo;
     int first;  // 1: start from x = f, y = 0 (inputs xin/y1in/y2in ignored)
     int img0;   // first image handled by this launch (grid = tiles per image * images of the chain)
+    int dbg;    // timing experiments only (results are wrong): 1 skip state loads, 2 skip stores, 4 no iterations
 };
 
 // 1-D tiling with halo: region length R, halo T, image length L.  Tile a covers region
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     const int M = A.M, N = A.N;
     const size_t base = (size_t)img * M * N;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
-    const bool first = A.first != 0;
+    const bool first = (A.first != 0) || (A.dbg & 1);
 
     // ---- prologue: every global load is issued before the first use (one memory round trip).
     // Out-of-image pixels read a clamped in-image address and are zeroed afterwards.
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     __syncthreads();
 
     const double rho = A.rho;
-    for (int it = 0; it < A.nit; ++it) {
+    const int nit = (A.dbg & 4) ? 0 : A.nit;
+    for (int it = 0; it < nit; ++it) {
         const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * (A.it0 + it);
         const double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
         double xb[PJ][PI];
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pi = 0; pi < PI; ++pi) {
             const int li = ti + TI * pi, lj = tj + TJ * pj;
             const int gi = oi + li, gj = oj + lj;
-            if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1) {
+            if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(A.dbg & 2)) {
                 const size_t idx = base + gi + (size_t)M * gj;
                 A.xout[idx] = x[pj][pi];
                 A.y1out[idx] = y1[pj][pi];

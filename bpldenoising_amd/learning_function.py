@@ -90,6 +90,8 @@ class TVSolver:
         self._lib.bpltv_default_params(C.byref(p))
         variant = kw.pop("variant", None)
         chains = kw.pop("chains", None)
+        dbg = kw.pop("dbg", None)
+        serialize = kw.pop("serialize_chains", None)
         for k, v in kw.items():
             if k in _IGNORED:
                 continue
@@ -102,6 +104,10 @@ class TVSolver:
             p.reserved[0] = int(variant)   # PDHG kernel variant (1-based), 0 = auto
         if chains is not None:
             p.reserved[1] = int(chains)    # independent launch chains in the hipGraph, 0 = auto
+        if serialize is not None:
+            p.reserved[2] = int(bool(serialize))  # replay launch chains one after the other (timing aid)
+        if dbg is not None:
+            p.reserved[3] = int(dbg)       # timing experiments only (wrong results), see PdhgArgs::dbg
         return p
 
     def _batch(self, a, what):
