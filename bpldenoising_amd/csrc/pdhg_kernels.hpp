@@ -145,9 +145,15 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                x[pj][pi] = A.xin[gidx[pj][pi]];
-                y1[pj][pi] = A.y1in[gidx[pj][pi]];
-                y2[pj][pi] = A.y2in[gidx[pj][pi]];
+                if (A.dbg & 64) {  // experiment: non-temporal loads
+                    x[pj][pi] = __builtin_nontemporal_load(&A.xin[gidx[pj][pi]]);
+                    y1[pj][pi] = __builtin_nontemporal_load(&A.y1in[gidx[pj][pi]]);
+                    y2[pj][pi] = __builtin_nontemporal_load(&A.y2in[gidx[pj][pi]]);
+                } else {
+                    x[pj][pi] = A.xin[gidx[pj][pi]];
+                    y1[pj][pi] = A.y1in[gidx[pj][pi]];
+                    y2[pj][pi] = A.y2in[gidx[pj][pi]];
+                }
             }
     }
 #pragma unroll
@@ -263,9 +269,23 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             const int gi = oi + li, gj = oj + lj;
             if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(A.dbg & 2)) {
                 const size_t idx = base + gi + (size_t)M * gj;
-                A.xout[idx] = x[pj][pi];
-                A.y1out[idx] = y1[pj][pi];
-                A.y2out[idx] = y2[pj][pi];
+                if (A.dbg & 16) {  // experiment: non-temporal stores
+                    __builtin_nontemporal_store(x[pj][pi], &A.xout[idx]);
+                    __builtin_nontemporal_store(y1[pj][pi], &A.y1out[idx]);
+                    __builtin_nontemporal_store(y2[pj][pi], &A.y2out[idx]);
+                } else if (!(A.dbg & 32)) {
+                    // write-through (sc1) stores: the state of this launch is read next by workgroups
+                    // on other XCDs, so it has to reach memory anyway; writing through while the
+                    // kernel still runs leaves no dirty L2 lines for the end-of-kernel release
+                    // (-0.9 us per launch on MI355X, profiles/README.md)
+                    __hip_atomic_store(&A.xout[idx], x[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&A.y1out[idx], y1[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&A.y2out[idx], y2[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    A.xout[idx] = x[pj][pi];
+                    A.y1out[idx] = y1[pj][pi];
+                    A.y2out[idx] = y2[pj][pi];
+                }
             }
         }
 }

@@ -55,9 +55,9 @@ def main():
     s.set_data(ub, f)
     res = []
     u_ref = None
-    for var in (1, 4, 5, 10):
-        for T in (4, 6, 8):
-            for chains in (1, 2, 5, 10):
+    for var in (1, 3, 4, 5, 7, 10):
+        for T in (4, 5, 6, 7, 8, 10):
+            for chains in (1, 2):
                 try:
                     u = s.denoise(0.1, fetch=True, maxiter=5000, variant=var, tile_iters=T, chains=chains)
                     if u_ref is None:
