@@ -8,7 +8,8 @@ from .learning_function import (FwdGradientOp, L2CostFunction, TVDenoise, TVSolv
                                 tv_op_learning_function)
 from .sharding import ShardedLearningFunction, shard_range
 from .datasets import testdataset, load_filelist_dataset
+from . import trbox
 
 __all__ = ["FwdGradientOp", "L2CostFunction", "TVDenoise", "TVSolver", "denoise",
            "tv_op_learning_function", "ShardedLearningFunction", "shard_range", "testdataset",
-           "load_filelist_dataset"]
+           "load_filelist_dataset", "trbox"]
