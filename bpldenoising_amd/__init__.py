@@ -5,11 +5,11 @@ Product path: libbpltv.so (hand-written HIP for gfx950, C ABI in include/bpltv.h
 is the thin host mirror of the reference's operator interface; it has no CPU fallback.
 """
 from .learning_function import (FwdGradientOp, L2CostFunction, TVDenoise, TVSolver, denoise,
-                                tv_op_learning_function)
+                                generate_cost, tv_op_learning_function)
 from .sharding import ShardedLearningFunction, shard_range
 from .datasets import testdataset, load_filelist_dataset
 from . import trbox
 
 __all__ = ["FwdGradientOp", "L2CostFunction", "TVDenoise", "TVSolver", "denoise",
-           "tv_op_learning_function", "ShardedLearningFunction", "shard_range", "testdataset",
+           "tv_op_learning_function", "generate_cost", "ShardedLearningFunction", "shard_range", "testdataset",
            "load_filelist_dataset", "trbox"]

@@ -60,10 +60,11 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 struct GraphKey {
     int maxiter, T, variant, am, an, chains;
     double rho, tau0, sigma0;
-    int accel, dbg;
+    int accel, dbg, nimg;
+    const void* state;
     bool operator<(const GraphKey& o) const {
-        return std::tie(maxiter, T, variant, am, an, chains, rho, tau0, sigma0, accel, dbg) <
-               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.chains, o.rho, o.tau0, o.sigma0, o.accel, o.dbg);
+        return std::tie(maxiter, T, variant, am, an, chains, rho, tau0, sigma0, accel, dbg, nimg, state) <
+               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.chains, o.rho, o.tau0, o.sigma0, o.accel, o.dbg, o.nimg, o.state);
     }
 };
 
@@ -86,6 +87,12 @@ struct bpltv_handle {
     // dataset + state
     double *d_ubar = nullptr, *d_f = nullptr;
     double* d_state[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    // current solve context: default = the O dataset images; a parameter sweep swaps in K*O slots
+    double* (*cur_state)[3] = nullptr;
+    int cur_nimg = 0, cur_astride = 0;
+    double* d_sweep[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    size_t sweep_cap = 0;  // images
+    double* d_sweep_cost = nullptr;
     int result_buf = 0;  // which state set holds the last result
     bool has_result = false;
     double* d_alpha = nullptr;
@@ -232,13 +239,13 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     pl->nTi = tile_count(M, V.RI, T);
     pl->nTj = tile_count(N, V.RJ, T);
     if (pl->nTi < 1 || pl->nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
-    pl->grid = pl->nTi * pl->nTj * h->O;
+    pl->grid = pl->nTi * pl->nTj * h->cur_nimg;
     // Independent image groups ("chains") of the launch graph: images never exchange data, so
     // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
     // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
     int ch = p.reserved[1];
-    if (ch <= 0) ch = (h->npx <= 256 * 256 && h->O >= 2) ? 2 : 1;  // two queues overlap launch latency
-    if (ch > h->O) ch = h->O;
+    if (ch <= 0) ch = (h->npx <= 256 * 256 && h->cur_nimg >= 2 && h->cur_nimg <= 64) ? 2 : 1;  // two queues overlap launch latency
+    if (ch > h->cur_nimg) ch = h->cur_nimg;
     pl->chains = ch;
     return BPLTV_OK;
 }
@@ -251,7 +258,7 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     const int tilesPerImg = pl.nTi * pl.nTj;
     int rc = BPLTV_OK;
     for (int c = 0; c < pl.chains && rc == BPLTV_OK; ++c) {
-        const int lo = (int)(((long)h->O * c) / pl.chains), hi = (int)(((long)h->O * (c + 1)) / pl.chains);
+        const int lo = (int)(((long)h->cur_nimg * c) / pl.chains), hi = (int)(((long)h->cur_nimg * (c + 1)) / pl.chains);
         if (hi <= lo) continue;
         hipGraph_t g = nullptr;
         HIPCHK(h, hipGraphCreate(&g, 0));
@@ -261,14 +268,15 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             PdhgArgs a;
             a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
-            a.M = h->M; a.N = h->N; a.O = h->O;
+            a.M = h->M; a.N = h->N; a.O = h->cur_nimg;
+            a.Odata = h->O; a.astride = h->cur_astride;
             a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
             a.img0 = lo;
             a.dbg = p.reserved[3];
             const int nxt = (it == 0) ? 0 : 1 - cur;
             a.first = (it == 0) ? 1 : 0;
-            a.xin = h->d_state[cur][0]; a.y1in = h->d_state[cur][1]; a.y2in = h->d_state[cur][2];
-            a.xout = h->d_state[nxt][0]; a.y1out = h->d_state[nxt][1]; a.y2out = h->d_state[nxt][2];
+            a.xin = h->cur_state[cur][0]; a.y1in = h->cur_state[cur][1]; a.y2in = h->cur_state[cur][2];
+            a.xout = h->cur_state[nxt][0]; a.y1out = h->cur_state[nxt][1]; a.y2out = h->cur_state[nxt][2];
             a.it0 = it;
             a.nit = std::min(pl.T, p.maxiter - it);
             void* kargs[] = {&a};
@@ -316,7 +324,8 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.rho = p.rho;
     a.am = h->last_am;
     a.an = h->last_an;
-    a.M = h->M; a.N = h->N; a.O = h->O;
+    a.M = h->M; a.N = h->N; a.O = h->cur_nimg;
+    a.Odata = h->O; a.astride = h->cur_astride;
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
     a.img0 = 0;
     a.dbg = p.reserved[3];
@@ -325,8 +334,8 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         const int nit = std::min(pl.T, it1 - it);
         const int nxt = (it == 0) ? 0 : 1 - cur;
         a.first = (it == 0) ? 1 : 0;
-        a.xin = h->d_state[cur][0]; a.y1in = h->d_state[cur][1]; a.y2in = h->d_state[cur][2];
-        a.xout = h->d_state[nxt][0]; a.y1out = h->d_state[nxt][1]; a.y2out = h->d_state[nxt][2];
+        a.xin = h->cur_state[cur][0]; a.y1in = h->cur_state[cur][1]; a.y2in = h->cur_state[cur][2];
+        a.xout = h->cur_state[nxt][0]; a.y1out = h->cur_state[nxt][1]; a.y2out = h->cur_state[nxt][2];
         a.it0 = it;
         a.nit = nit;
         V.launch(a, pl.grid, h->stream);
@@ -375,10 +384,13 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     int buf = 0, launches = 0;
     if (p.maxiter == 0) {  // u = f
         for (int c = 0; c < 3; ++c) {
-            if (c == 0)
-                HIPCHK(h, hipMemcpyAsync(h->d_state[0][0], h->d_f, h->tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-            else
-                HIPCHK(h, hipMemsetAsync(h->d_state[0][c], 0, h->tot * sizeof(double), h->stream));
+            if (c == 0) {
+                for (int r = 0; r < h->cur_nimg / h->O; ++r)
+                    HIPCHK(h, hipMemcpyAsync(h->cur_state[0][0] + (size_t)r * h->tot, h->d_f, h->tot * sizeof(double),
+                                             hipMemcpyDeviceToDevice, h->stream));
+            } else {
+                HIPCHK(h, hipMemsetAsync(h->cur_state[0][c], 0, (size_t)h->cur_nimg * h->npx * sizeof(double), h->stream));
+            }
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->result_buf = 0;
@@ -391,7 +403,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (!chunked) {
         bool done = false;
         if (p.use_graph) {
-            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3]};
+            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)h->cur_state[0][0]};
             auto it = h->graphs.find(key);
             const int nl = (p.maxiter + pl.T - 1) / pl.T;
             if (it == h->graphs.end()) {
@@ -462,7 +474,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->has_result = true;
     const bool amap = (h->last_am == h->M && h->last_an == h->N) && !(h->M == 1 && h->N == 1);
     h->st.bytes_per_px_iter = amap ? 64.0 : 56.0;
-    h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->tot * h->st.iterations;
+    h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->npx * h->cur_nimg * h->st.iterations;
     return BPLTV_OK;
 }
 
@@ -680,6 +692,9 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     HIPCHK(h, hipMalloc((void**)&h->d_f, h->tot * sizeof(double)));
     for (int s = 0; s < 2; ++s)
         for (int c = 0; c < 3; ++c) HIPCHK(h, hipMalloc((void**)&h->d_state[s][c], h->tot * sizeof(double)));
+    h->cur_state = h->d_state;
+    h->cur_nimg = O;
+    h->cur_astride = 0;
     HIPCHK(h, hipMalloc((void**)&h->d_perimg, (size_t)O * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_scalar, 4 * sizeof(double)));
     // LDS above 64 KB needs the opt-in attribute
@@ -705,8 +720,11 @@ int bpltv_destroy(bpltv_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c) {
             if (h->d_state[s][c]) (void)hipFree(h->d_state[s][c]);
+            if (h->d_sweep[s][c]) (void)hipFree(h->d_sweep[s][c]);
+        }
+    if (h->d_sweep_cost) (void)hipFree(h->d_sweep_cost);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -861,6 +879,71 @@ int bpltv_gradient(bpltv_t* h, const double* u, const double* ubar, const double
     HIPCHK(h, hipMemcpyAsync(grad_out, h->d_partial + 1, sizeof(double) * (size_t)am * an, hipMemcpyDeviceToHost,
                              h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const bpltv_params* pp, double* cost_out,
+                double* u_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (!alphas || !cost_out || K < 1) return set_err(h, BPLTV_E_ARG, "sweep: null pointer or K < 1");
+    if (am < 1 || an < 1 || am > h->M || an > h->N) return set_err(h, BPLTV_E_ARG, "sweep: bad parameter shape %dx%d", am, an);
+    if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    p.check_every = 0;  // the gap kernels address the dataset context only
+    const size_t nimg = (size_t)K * h->O, npar = (size_t)am * an;
+    if (h->sweep_cap < nimg) {
+        drop_graphs(h);
+        for (int s = 0; s < 2; ++s)
+            for (int c = 0; c < 3; ++c) {
+                if (h->d_sweep[s][c]) HIPCHK(h, hipFree(h->d_sweep[s][c]));
+                h->d_sweep[s][c] = nullptr;
+                HIPCHK(h, hipMalloc((void**)&h->d_sweep[s][c], nimg * h->npx * sizeof(double)));
+            }
+        if (h->d_sweep_cost) HIPCHK(h, hipFree(h->d_sweep_cost));
+        HIPCHK(h, hipMalloc((void**)&h->d_sweep_cost, nimg * sizeof(double)));
+        h->sweep_cap = nimg;
+    }
+    // all K parameter blocks live in the alpha buffer; problem k*O + i uses block k and image i
+    if (h->alpha_cap < K * npar) {
+        drop_graphs(h);
+        int rc = ensure(h, &h->d_alpha, &h->alpha_cap, K * npar);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_alpha, alphas, K * npar * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->last_am = am;
+    h->last_an = an;
+    h->cur_state = h->d_sweep;
+    h->cur_nimg = (int)nimg;
+    h->cur_astride = (int)npar;
+    int rc = run_pdhg(h, p);
+    const int rb = h->result_buf;
+    h->cur_state = h->d_state;
+    h->cur_nimg = h->O;
+    h->cur_astride = 0;
+    h->has_result = false;  // the default context holds no result of this call
+    if (rc) return rc;
+    // loss of every problem against ubar[img % O], then summed per parameter on the host
+    const int nblk = 16;
+    rc = ensure(h, &h->d_red, &h->red_cap, nimg * nblk * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cost_partial_mod_kernel, dim3(nblk, (unsigned)nimg), dim3(256), 0, h->stream, h->d_sweep[rb][0],
+                       h->d_ubar, (int)h->npx, h->O, h->d_red);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, nblk, (int)nimg, 0.5,
+                       h->d_sweep_cost, (double*)nullptr);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> per(nimg);
+    HIPCHK(h, hipMemcpyAsync(per.data(), h->d_sweep_cost, nimg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u_out)
+        HIPCHK(h, hipMemcpyAsync(u_out, h->d_sweep[rb][0], nimg * h->npx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < K; ++k) {
+        double sacc = 0.0;
+        for (int i = 0; i < h->O; ++i) sacc += per[(size_t)k * h->O + i];
+        cost_out[k] = sacc;
+    }
     h->st.total_ms = wt.ms();
     return BPLTV_OK;
 }

@@ -40,6 +40,9 @@ struct PdhgArgs {
     int nTi, nTj, halo;
     int first;  // 1: start from x = f, y = 0 (inputs xin/y1in/y2in ignored)
     int img0;   // first image handled by this launch (grid = tiles per image * images of the chain)
+    int Odata;  // images in the dataset; image `img` of the solve uses f[img % Odata] and the
+                // parameter block alpha + (img / Odata) * astride (parameter sweeps: K*Odata problems)
+    int astride;
     int dbg;    // timing experiments only (results are wrong): 1 skip state loads, 2 skip stores, 4 no iterations
 };
 
@@ -115,14 +118,16 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
     const int M = A.M, N = A.N;
-    const size_t base = (size_t)img * M * N;
+    const size_t base = (size_t)img * M * N;                 // state planes: one slot per solve image
+    const size_t fbase = (size_t)(img % A.Odata) * M * N;    // dataset planes
+    const double* __restrict__ alpha = A.alpha + (size_t)(img / A.Odata) * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
     const bool first = (A.first != 0) || (A.dbg & 1);
 
     // ---- prologue: every global load is issued before the first use (one memory round trip).
     // Out-of-image pixels read a clamped in-image address and are zeroed afterwards.
     double x[PJ][PI], y1[PJ][PI], y2[PJ][PI], f[PJ][PI], al[PJ][PI];
-    size_t gidx[PJ][PI], aidx[PJ][PI];
+    size_t gidx[PJ][PI], fidx[PJ][PI], aidx[PJ][PI];
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             const int li = ti + TI * pi, lj = tj + TJ * pj;
             const int gi = min(oi + li, M - 1), gj = min(oj + lj, N - 1);
             gidx[pj][pi] = base + gi + (size_t)M * gj;
+            fidx[pj][pi] = fbase + gi + (size_t)M * gj;
             size_t ai = 0;  // scalar alpha
             if (amode == 2) {
                 ai = gi + (size_t)M * gj;
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            f[pj][pi] = A.f[gidx[pj][pi]];
-            al[pj][pi] = A.alpha[aidx[pj][pi]];
+            f[pj][pi] = A.f[fidx[pj][pi]];
+            al[pj][pi] = alpha[aidx[pj][pi]];
         }
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj)
@@ -324,6 +330,21 @@ __global__ __launch_bounds__(256) void cost_partial_kernel(const double* __restr
     double s = 0.0;
     for (int q = blockIdx.x * 256 + threadIdx.x; q < npx; q += gridDim.x * 256) {
         const double d = u[base + q] - ubar[base + q];
+        s = __builtin_fma(d, d, s);
+    }
+    s = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// Same for a parameter sweep: problem blockIdx.y compares with ubar[blockIdx.y % Odata].
+__global__ __launch_bounds__(256) void cost_partial_mod_kernel(const double* __restrict__ u,
+                                                               const double* __restrict__ ubar, int npx,
+                                                               int Odata, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const size_t base = (size_t)blockIdx.y * npx, bbase = (size_t)(blockIdx.y % Odata) * npx;
+    double s = 0.0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < npx; q += gridDim.x * 256) {
+        const double d = u[base + q] - ubar[bbase + q];
         s = __builtin_fma(d, d, s);
     }
     s = block_sum<256>(s, sh);

@@ -174,6 +174,24 @@ class TVSolver:
                                              C.byref(p), _ptr(grad)))
         return float(grad[0]) if scalar else grad.reshape(an, am)
 
+    def sweep(self, alphas, fetch_u=False, **kw):
+        """costs[k] = 0.5*||denoise(f, alphas[k]) - ubar||^2 for K parameters in one batched solve
+        (generate_cost / generate_2d_cost, /root/reference/src/BPLDenoising.jl:92-111,136-158).
+        alphas: (K,) scalars or (K, n, m) parameter matrices."""
+        a = np.ascontiguousarray(alphas, dtype=np.float64)
+        if a.ndim == 1:
+            K, am, an = a.shape[0], 1, 1
+        elif a.ndim == 3:
+            K, an, am = a.shape
+        else:
+            raise ValueError("alphas must have shape (K,) or (K, n, m)")
+        p = self.params(**kw)
+        costs = np.empty(K)
+        u = np.empty((K, self.O, self.N, self.M)) if fetch_u else None
+        self._check(self._lib.bpltv_sweep(self._h, _ptr(a), K, am, an, C.byref(p), _ptr(costs),
+                                          _ptr(u) if fetch_u else None))
+        return (costs, u) if fetch_u else costs
+
     def u_device_ptr(self):
         p = C.c_void_p()
         self._check(self._lib.bpltv_u_device(self._h, C.byref(p)))
@@ -252,6 +270,15 @@ def TVDenoise(data, parameter, **kwargs):
     """/root/reference/src/BPLDenoising.jl:41-82: the same solve with maxiter = 10000."""
     kwargs.setdefault("maxiter", 10000)
     return denoise(data, parameter, FwdGradientOp(), **kwargs)
+
+
+def generate_cost(data, parameters, **kwargs):
+    """cost curve over a parameter range -- /root/reference/src/BPLDenoising.jl:92-111
+    (`generate_cost`: loop of TVDenoise + L2CostFunction, maxiter = 10000), as ONE batched solve.
+    data = (ubar, f); parameters: (K,) scalars or (K, n, m) matrices (generate_2d_cost: (K, 1, 2))."""
+    kwargs.setdefault("maxiter", 10000)
+    s = _solver_for(data[0], data[1])
+    return s.sweep(parameters, **kwargs)
 
 
 def L2CostFunction(u, true_):

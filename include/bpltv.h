@@ -137,6 +137,15 @@ int bpltv_grad_fwd_adjoint(bpltv_t *h, const double *y1, const double *y2, doubl
 int bpltv_gradient(bpltv_t *h, const double *u, const double *ubar, const double *alpha, int am,
                    int an, int reg, const bpltv_params *p, double *grad_out);
 
+/* Forward-only parameter sweep: generate_cost / generate_2d_cost (src/BPLDenoising.jl:92-111,
+ * :136-158) evaluate cost(alpha_k) = 0.5*||TVDenoise(f, alpha_k) - ubar||^2 for a range of parameters,
+ * one solve after the other.  Here the K parameter blocks (each am x an, column major, K*am*an
+ * doubles) times the O resident images form ONE batch of K*O independent ROF problems -- the second
+ * data-parallel axis that fills a GPU even with a single image.  cost_out: K doubles; u_out: NULL
+ * or K*M*N*O doubles (parameter-major).  Use maxiter = 10000 for the TVDenoise setting. */
+int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const bpltv_params *p,
+                double *cost_out, double *u_out);
+
 int bpltv_stats(bpltv_t *h, bpltv_stats_t *out);
 const char *bpltv_last_error(bpltv_t *h);
 int bpltv_version(void);

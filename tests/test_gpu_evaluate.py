@@ -158,3 +158,64 @@ def test_reference_named_entry_points(oracle):
     assert np.array_equal(ud, u0)
     with pytest.raises(TypeError):
         B.denoise(f, 0.1, op=object())
+
+
+def test_parameter_sweep_matches_individual_solves(gpu_solver_cls, oracle):
+    """generate_cost / generate_2d_cost (/root/reference/src/BPLDenoising.jl:92-111,136-158) as one
+    batched solve: every (parameter, image) problem is bit-identical to its stand-alone solve."""
+    ub, f = synth_batch(2, 64, 48, seed=26)
+    s = gpu_solver_cls(48, 64, 2)
+    s.set_data(ub, f)
+    alphas = np.array([0.0, 0.02, 0.05, 0.1, 0.2, 0.4, 0.8])
+    costs, u = s.sweep(alphas, fetch_u=True, maxiter=400)
+    assert costs.shape == (7,) and u.shape == (7, 2, 64, 48)
+    for k, a in enumerate(alphas):
+        uk = s.denoise(float(a), maxiter=400)
+        assert np.array_equal(u[k], uk)
+        assert np.isclose(costs[k], oracle.cost(uk, ub), rtol=1e-13)
+    assert np.array_equal(u[3], oracle.pdhg(f, 0.1, maxiter=400))
+    # 2-D sweep with a 2x1 parameter [a; b] (generate_2d_cost)
+    grid = np.array([[[a, b]] for a in (0.05, 0.1) for b in (0.02, 0.2, 0.3)])      # (K, n=1, m=2)
+    costs2, u2 = s.sweep(grid, fetch_u=True, maxiter=300)
+    for k in range(grid.shape[0]):
+        assert np.array_equal(u2[k], s.denoise(grid[k], maxiter=300))
+    # a default-context solve afterwards is unaffected
+    assert np.array_equal(s.denoise(0.1, maxiter=400), u[3])
+    s.close()
+
+
+def test_generate_cost_entry_point(oracle):
+    import bpldenoising_amd as B
+    ub, f = T.load_dataset(DATASETS_NPZ, "cameraman_128_5")
+    par = np.linspace(0.0, 0.055, 12)          # minimum of the curve near alpha = 0.015-0.02
+    costs = B.generate_cost((ub, f), par, maxiter=1000)
+    k = int(np.argmin(costs))
+    assert 0 < k < 11                                   # the cost curve has an interior minimum
+    assert np.isclose(costs[5], oracle.cost(oracle.pdhg(f, par[5], maxiter=1000), ub), rtol=1e-13)
+
+
+def test_sharded_learning_function_rccl_single_rank(gpu_solver_cls, oracle):
+    """The N-rank host path with the RCCL backend on one rank: partial vector written to HBM by
+    bpltv_evaluate_device, all-reduced by torch.distributed (nccl == RCCL), u fetched from HBM."""
+    import os
+    import torch.distributed as dist
+    from bpldenoising_amd import ShardedLearningFunction
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ub, f = synth_batch(3, 48, 48, seed=27)
+        fn = ShardedLearningFunction((ub, f))
+        assert fn.device_reduce and (fn.lo, fn.hi) == (0, 3)
+        u, cost, grad = fn(P22, 0.1, maxiter=300)
+        u0 = oracle.pdhg(f, P22, maxiter=300)
+        assert np.array_equal(u, u0)
+        assert np.isclose(cost, oracle.cost(u0, ub), rtol=1e-13)
+        assert np.allclose(grad, oracle.gradient(P22, u0, ub), rtol=1e-6)
+        u, cost, g = fn(0.1, 0.1, maxiter=300, fetch_u=False)
+        assert u is None and isinstance(g, float)
+    finally:
+        if created:
+            dist.destroy_process_group()
