@@ -35,14 +35,14 @@ struct Variant {
 
 template <int PI, int PJ, int TI, int TJ>
 void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
-    constexpr size_t lds = sizeof(double) * 3 * (PI * TI) * (PJ * TJ);
+    constexpr size_t lds = pdhg_lds_bytes(PI * TI, PJ * TJ);
     hipLaunchKernelGGL((pdhg_tile_kernel<PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
 }
 
 #define VAR(PI, PJ, TI, TJ)                                                                    \
     { PI * TI, PJ * TJ, TI * TJ, &launch_variant<PI, PJ, TI, TJ>,                               \
       reinterpret_cast<const void*>(&pdhg_tile_kernel<PI, PJ, TI, TJ>),                         \
-      sizeof(double) * 3 * (PI * TI) * (PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
+      pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread   (large images, deep blocking)
@@ -244,7 +244,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
     // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
     int ch = p.reserved[1];
-    if (ch <= 0) ch = (h->npx <= 256 * 256 && h->cur_nimg >= 2 && h->cur_nimg <= 64) ? 2 : 1;  // two queues overlap launch latency
+    if (ch <= 0) ch = 1;  // with write-through state stores one chain is as fast as two and steadier (tools/gpu_ab.py)
     if (ch > h->cur_nimg) ch = h->cur_nimg;
     pl->chains = ch;
     return BPLTV_OK;
@@ -699,11 +699,11 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     HIPCHK(h, hipMalloc((void**)&h->d_scalar, 4 * sizeof(double)));
     // LDS above 64 KB needs the opt-in attribute
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 32, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * 8));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(64, 64)));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<4, 4, 16, 16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 64 * 8));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(64, 64)));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 64, 16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 32 * 8));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(128, 32)));
     return BPLTV_OK;
 }
 

@@ -21,6 +21,12 @@
 
 namespace bpltv {
 
+// LDS bytes of pdhg_tile_kernel for a region RI x RJ: y1 plane with a guard column, y2 plane with a
+// guard row, xbar plane with RI+1 pad cells.
+constexpr size_t pdhg_lds_bytes(int RI, int RJ) {
+    return sizeof(double) * ((size_t)RJ * (RI + 1) + (size_t)(RJ + 1) * RI + (size_t)RJ * RI + RI + 1);
+}
+
 constexpr int TAB_STRIDE = 8;  // doubles per iteration row: tau, sigma, omega, 1/(1+tau), 1+omega, pad
 
 struct PdhgArgs {
@@ -102,10 +108,17 @@ __device__ __forceinline__ double rsqrt_nr(double n2) {
 template <int PI, int PJ, int TI, int TJ>
 __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     constexpr int RI = PI * TI, RJ = PJ * TJ;
+    // LDS planes with guard cells so that the neighbour reads need no select:
+    //   sy1: rows of RI+1, a leading zero column  -> y1(i-1,j) at li = 0 reads 0
+    //   sy2: a leading zero row                   -> y2(i,j-1) at lj = 0 reads 0
+    //   sxb: RI+1 trailing pad cells              -> xbar(i+1,j), xbar(i,j+1) at the region edge read
+    //        finite garbage (zeros); there the result is either masked by the image-border test or
+    //        lies in the halo that is never written back
+    constexpr int S1 = RI + 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sy1 = smem;
-    double* sy2 = smem + RI * RJ;
-    double* sxb = smem + 2 * RI * RJ;
+    double* sy1 = smem;                              // [RJ][S1]
+    double* sy2 = smem + RJ * S1;                    // [RJ+1][RI]
+    double* sxb = smem + RJ * S1 + (RJ + 1) * RI;    // [RJ][RI] + RI + 1
 
     const int tid = threadIdx.x;
     const int ti = tid % TI, tj = tid / TI;
@@ -183,16 +196,31 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             if (!in) {
                 f[pj][pi] = 0.0; x[pj][pi] = 0.0; y1[pj][pi] = 0.0; y2[pj][pi] = 0.0; al[pj][pi] = 0.0;
             }
-            sy1[lj * RI + li] = y1[pj][pi];
-            sy2[lj * RI + li] = y2[pj][pi];
+            sy1[lj * S1 + li + 1] = y1[pj][pi];
+            sy2[(lj + 1) * RI + li] = y2[pj][pi];
         }
+    for (int e = threadIdx.x; e < RJ; e += TI * TJ) sy1[e * S1] = 0.0;
+    for (int e = threadIdx.x; e < RI; e += TI * TJ) sy2[e] = 0.0;
+    for (int e = threadIdx.x; e < RI + 1; e += TI * TJ) sxb[RI * RJ + e] = 0.0;
     __syncthreads();
 
     const double rho = A.rho;
     const int nit = (A.dbg & 4) ? 0 : A.nit;
+    // image-border masks (Neumann): hoisted out of the iteration loop
+    bool m1[PJ][PI], m2[PJ][PI];
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+        for (int pi = 0; pi < PI; ++pi) {
+            m1[pj][pi] = (oi + ti + TI * pi) < M - 1;
+            m2[pj][pi] = (oj + tj + TJ * pj) < N - 1;
+        }
+    // step sizes of iteration `it`: scalar loads, issued one iteration ahead
+    const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * A.it0;
+    double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
     for (int it = 0; it < nit; ++it) {
-        const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * (A.it0 + it);
-        const double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+        const double* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
+        const double ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
         double xb[PJ][PI];
         // ---- primal step: x <- prox_{tau*fidelity}(x - tau * G^T y); over-relaxation.
         // LDS reads are unconditional (clamped index) and selected afterwards: one wait for all.
@@ -202,9 +230,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
-                const int l = lj * RI + li;
-                y1m[pj][pi] = sy1[(li > 0) ? l - 1 : l];
-                y2m[pj][pi] = sy2[(lj > 0) ? l - RI : l];
+                y1m[pj][pi] = sy1[lj * S1 + li];        // (li-1)+1: guard column at li = 0
+                y2m[pj][pi] = sy2[lj * RI + li];        // (lj-1)+1: guard row at lj = 0
             }
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
@@ -212,9 +239,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const int l = lj * RI + li;
-                const double a1 = (li > 0) ? y1m[pj][pi] : 0.0;
-                const double a2 = (lj > 0) ? y2m[pj][pi] : 0.0;
-                const double div = (a1 - y1[pj][pi]) + (a2 - y2[pj][pi]);
+                const double div = (y1m[pj][pi] - y1[pj][pi]) + (y2m[pj][pi] - y2[pj][pi]);
                 const double tt = div - f[pj][pi];
                 const double xo = x[pj][pi];
                 const double xn = __builtin_fma(-tau, tt, xo) * inv1ptau;
@@ -232,19 +257,17 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const int l = lj * RI + li;
-                xp1[pj][pi] = sxb[(li < RI - 1) ? l + 1 : l];
-                xpM[pj][pi] = sxb[(lj < RJ - 1) ? l + RI : l];
+                xp1[pj][pi] = sxb[l + 1];
+                xpM[pj][pi] = sxb[l + RI];
             }
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
-                const int l = lj * RI + li;
-                const int gi = oi + li, gj = oj + lj;
                 const double b = xb[pj][pi];
-                const double d1 = (li < RI - 1 && gi < M - 1) ? xp1[pj][pi] - b : 0.0;
-                const double d2 = (lj < RJ - 1 && gj < N - 1) ? xpM[pj][pi] - b : 0.0;
+                const double d1 = m1[pj][pi] ? xp1[pj][pi] - b : 0.0;
+                const double d2 = m2[pj][pi] ? xpM[pj][pi] - b : 0.0;
                 const double a = al[pj][pi];
                 double y1n = __builtin_fma(sigma, d1, y1[pj][pi]);
                 double y2n = __builtin_fma(sigma, d2, y2[pj][pi]);
@@ -261,9 +284,10 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 }
                 y1[pj][pi] = y1n;
                 y2[pj][pi] = y2n;
-                sy1[l] = y1n;
-                sy2[l] = y2n;
+                sy1[lj * S1 + li + 1] = y1n;
+                sy2[(lj + 1) * RI + li] = y2n;
             }
+        tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
         __syncthreads();
     }
 
