@@ -91,6 +91,17 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    # the native library normally travels prebuilt; build it (rank 0) if this is a bare checkout
+    lib_so = os.path.join(ROOT, "bpldenoising_amd", "libbpltv.so")
+    if not os.path.exists(lib_so):
+        if local_rank == 0:
+            import __graft_entry__ as ge
+            ge.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(lib_so) and time.time() - t_wait < 600:
+                time.sleep(1.0)
+            time.sleep(2.0)
     from bpldenoising_amd import TVSolver, shard_range
 
     M = N = args.size

@@ -206,14 +206,18 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
 
     const double rho = A.rho;
     const int nit = (A.dbg & 4) ? 0 : A.nit;
-    // image-border masks (Neumann): hoisted out of the iteration loop
-    bool m1[PJ][PI], m2[PJ][PI];
+    // Neumann border without a select in the loop: at the last image row/column (and outside the
+    // image) the "neighbour" read is redirected to the pixel's own xbar cell, so the forward
+    // difference is exactly +0.  The LDS offsets are computed once per launch.
+    int n1[PJ][PI], n2[PJ][PI];
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            m1[pj][pi] = (oi + ti + TI * pi) < M - 1;
-            m2[pj][pi] = (oj + tj + TJ * pj) < N - 1;
+            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const int l = lj * RI + li;
+            n1[pj][pi] = l + (((oi + li) < M - 1) ? 1 : 0);
+            n2[pj][pi] = l + (((oj + lj) < N - 1) ? RI : 0);
         }
     // step sizes of iteration `it`: scalar loads, issued one iteration ahead
     const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * A.it0;
@@ -255,10 +259,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const int li = ti + TI * pi, lj = tj + TJ * pj;
-                const int l = lj * RI + li;
-                xp1[pj][pi] = sxb[l + 1];
-                xpM[pj][pi] = sxb[l + RI];
+                xp1[pj][pi] = sxb[n1[pj][pi]];
+                xpM[pj][pi] = sxb[n2[pj][pi]];
             }
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const double b = xb[pj][pi];
-                const double d1 = m1[pj][pi] ? xp1[pj][pi] - b : 0.0;
-                const double d2 = m2[pj][pi] ? xpM[pj][pi] - b : 0.0;
+                const double d1 = xp1[pj][pi] - b;
+                const double d2 = xpM[pj][pi] - b;
                 const double a = al[pj][pi];
                 double y1n = __builtin_fma(sigma, d1, y1[pj][pi]);
                 double y2n = __builtin_fma(sigma, d2, y2[pj][pi]);
