@@ -406,7 +406,11 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)h->cur_state[0][0]};
             auto it = h->graphs.find(key);
             const int nl = (p.maxiter + pl.T - 1) / pl.T;
-            if (it == h->graphs.end()) {
+            if (it == h->graphs.end() && h->graphs.size() >= 16) {  // bounded cache
+                drop_graphs(h);
+                it = h->graphs.end();
+            }
+            if (it == h->graphs.end() && nl <= 50000) {  // longer sequences are launched eagerly
                 std::vector<hipGraphExec_t> ex;
                 if (build_graphs(h, p, pl, d_tab, &ex) == BPLTV_OK && !ex.empty()) {
                     h->graphs[key] = ex;
@@ -526,8 +530,8 @@ int adj_alloc(bpltv_t* h) {
 }
 
 // Adjoint gradient of the images (d_u, d_ubar) on the device; result (am*an doubles) -> d_out.
-int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
-                 double* d_out) {
+int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
+                      double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
@@ -537,6 +541,7 @@ int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, c
     double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
     double kact = 1.0 / (patch ? std::sqrt(eps) : eps);  // TVLearningFunctionVec.jl:128 / :245
     if (kact > kcap) kact = kcap;
+    kact *= kappa_scale;
     const int nref = p.refine < 0 ? 3 : p.refine;
     AdjCoef C;
     C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;
@@ -592,6 +597,20 @@ int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, c
     }
     h->st.adjoint_residual = worst;
     return BPLTV_OK;
+}
+
+// The reduced system is SPD, but its active-set weight (up to 1e14) sits 14 digits above the O(1)
+// terms; should rounding ever produce a non-positive pivot, retry with a 100x smaller weight
+// (1e12 still reproduces the hard-constraint limit to ~1e-5).
+int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
+                 double* d_out) {
+    double scale = 1.0;
+    int rc = BPLTV_OK;
+    for (int attempt = 0; attempt < 3; ++attempt, scale *= 1e-2) {
+        rc = run_gradient_once(h, d_u, d_ubar, reg, p, d_out, scale);
+        if (rc != BPLTV_E_NUMERIC) break;
+    }
+    return rc;
 }
 
 bpltv_params resolve(const bpltv_params* p) {
