@@ -220,7 +220,7 @@ def main():
                          "bytes_per_px_iter": bytes_px},
             "pdhg_event_ms_per_step": ev_ms / args.steps,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             from oracle import c_oracle as co
             cpu_iters = args.cpu_iters or min(args.iters, 5000 if M * N * args.images <= 200000 else 20)
             fb = f_full if args.scaling == "weak" else f_full
