@@ -231,12 +231,20 @@ def main():
             t1 = time.perf_counter()
             co.pdhg(fb, alpha, maxiter=cpu_iters, nthreads=nth)
             cn = time.perf_counter() - t1
+            cpu_adj = None
+            if args.evaluate and M <= 138:
+                # CPU share of one evaluation: the oracle's banded adjoint solve, one image
+                u1 = co.pdhg(fb[:1], alpha, maxiter=min(cpu_iters, 500), nthreads=1)
+                t1 = time.perf_counter()
+                co.gradient(alpha, u1, ub_full[:1])
+                cpu_adj = time.perf_counter() - t1
             out["cpu_baseline"] = {
                 "value": cpu_iters / c1, "unit": "PDHG iterations/s of the same %dx%dx%d batch" % (args.images, N, M),
                 "cores": 1, "kind": "port",
                 "sample": "%d iterations of the full batch, oracle/bpltv_oracle.c (gcc -O2), 1 thread (stock Julia runs the reference serially)" % cpu_iters,
                 "all_cores": {"value": cpu_iters / cn, "cores": nth, "note": "OpenMP over images"},
                 "host_cpus": os.cpu_count(),
+                "adjoint_s_per_image": cpu_adj,
             }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -62,7 +62,12 @@ typedef struct bpltv_params {
     int use_graph;       /* 1 (default): replay the launch sequence from a hipGraph               */
     double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
     int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3)   */
-    int reserved[5];
+    int reserved[5];     /* tuning / measurement knobs, 0 = default:
+                            [0] PDHG kernel variant (1-based index into the variant table of bpltv.hip)
+                            [1] number of independent launch chains (image groups replayed concurrently)
+                            [2] 1 = replay those chains one after the other (isolated kernel timing)
+                            [3] timing-experiment bit mask (results are wrong when set; see PdhgArgs::dbg)
+                            [4] unused                                                          */
 } bpltv_params;
 
 typedef struct bpltv_stats {
