@@ -79,7 +79,7 @@ struct TabKey {
 }  // namespace
 
 struct bpltv_handle {
-    int M = 0, N = 0, O = 0, device = 0;
+    int M = 0, N = 0, O = 0, device = 0, ncu = 0;
     size_t npx = 0, tot = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -228,7 +228,23 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
     const Variant& V = kVariants[v];
     int T = p.tile_iters;
-    if (T <= 0) T = 8;  // measured best on MI355X for both the 32x32 and the 64x64 region (profiles/)
+    if (T <= 0 && v == 0) {
+        // Fusion depth from a launch-cost model fitted on MI355X (tools/gpu_o1.py): a launch costs a
+        // fixed ~4.5 us plus T iterations of ~0.47 us while every CU holds at most one workgroup,
+        // ~0.94 us per round of two co-resident workgroups per CU beyond that.  Deeper fusion means
+        // fewer launches but smaller cores, i.e. more (redundant) tiles.  Results do not depend on T.
+        double best = 1e300;
+        const int ncu = h->ncu > 0 ? h->ncu : 256;
+        for (int t = 2; t <= 12; ++t) {
+            const int a = tile_count(M, V.RI, t), b = tile_count(N, V.RJ, t);
+            if (a < 1 || b < 1) continue;
+            const double tiles = (double)a * b * h->cur_nimg;
+            const double per_iter = (tiles <= ncu) ? 0.47 : 0.94 * std::ceil(tiles / (2.0 * ncu));
+            const double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
+            if (cost < best) { best = cost; T = t; }
+        }
+    }
+    if (T <= 0) T = 8;  // 64x64-region variants: measured best on MI355X (profiles/)
     // the halo must leave a core when the image is larger than the region
     auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
     int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
@@ -705,6 +721,10 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     h->st.last_gap = -1.0;
     *out = h;  // returned even on failure below so that bpltv_last_error works; caller destroys
     HIPCHK(h, hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount;
+    }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
     HIPCHK(h, hipMalloc((void**)&h->d_ubar, h->tot * sizeof(double)));
