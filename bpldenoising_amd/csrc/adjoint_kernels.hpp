@@ -128,6 +128,36 @@ __device__ __forceinline__ double band_init(const double* __restrict__ band4, si
     return v;
 }
 
+// Same matrix in the reversed ordering k' = n-1-k (used by the bottom-up half of the twisted
+// factorisation): entry (k'+d, k') of the reversed matrix is A[k][k-d], k = n-1-k'.
+__device__ __forceinline__ double band_init_rev(const double* __restrict__ band4, size_t tot, size_t ib,
+                                                int n, int kp, int d, int M) {
+    const int k = n - 1 - kp, j = k - d;
+    if (j < 0) return 0.0;
+    double v = 0.0;
+    if (d == 0) v += band4[ib + k];
+    if (d == 1) v += band4[tot + ib + j];
+    if (d == M - 1) v += band4[2 * tot + ib + j];
+    if (d == M) v += band4[3 * tot + ib + j];
+    return v;
+}
+
+// Split of the n columns for the twisted (two-sided) factorisation: the top half eliminates
+// [0, m) downwards, the bottom half eliminates the last nbot columns upwards (both multiples of the
+// panel width), the nm = n - m - nbot >= bw middle columns are factored last as a dense block.
+constexpr int ADJ_G = 64;  // granularity of the split = block size of the substitution kernels
+struct AdjSplit { int m, nbot, nm; };
+__host__ __device__ inline AdjSplit adj_split(int n, int bw, int NB = ADJ_G) {
+    AdjSplit s;
+    int half = (n - bw) / 2;
+    if (half < 0) half = 0;
+    s.m = (half / NB) * NB;
+    s.nbot = ((n - bw - s.m) / NB) * NB;
+    if (s.nbot < 0) s.nbot = 0;
+    s.nm = n - s.m - s.nbot;
+    return s;
+}
+
 // Broadcast of lane `src` (wave-uniform, a constant after unrolling) through SGPRs: v_readlane_b32,
 // a few cycles -- not ds_bpermute, whose ~100-cycle latency would sit in the substitution chain.
 __device__ __forceinline__ double readlane_f64(double v, int src) {
@@ -164,7 +194,9 @@ constexpr int ADJ_FT = 512;         // threads of the factorisation workgroup (2
 
 template <int NB, int MC>  // MC: compile-time M (0 = run-time)
 __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __restrict__ band4, int Mrt, int N,
-                                                          int O, double* __restrict__ L,
+                                                          int O, double* __restrict__ L0,
+                                                          double* __restrict__ L1, int twisted,
+                                                          double* __restrict__ dump,
                                                           int* __restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int M = MC ? MC : Mrt;
@@ -176,10 +208,20 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
     const size_t tot = (size_t)n * O;
     const size_t ib = (size_t)img * n;
     const int tid = threadIdx.x;
+    // twisted: blockIdx.y = 0 eliminates columns [0, m) of A, blockIdx.y = 1 the first nbot columns
+    // of the reversed matrix; both leave their trailing window (the middle block) in `dump`.
+    const int rev = twisted ? (int)blockIdx.y : 0;
+    const AdjSplit sp = adj_split(n, bw);
+    const int ncols = twisted ? (rev ? sp.nbot : sp.m) : n;
+    double* __restrict__ L = rev ? L1 : L0;
+    auto A0 = [&](int c, int d) -> double {  // initial entry (c+d, c) in this side's ordering
+        if (c >= n) return d == 0 ? 1.0 : 0.0;
+        return rev ? band_init_rev(band4, tot, ib, n, c, d, M) : band_init(band4, tot, ib + c, d, M);
+    };
 
     for (int e = tid; e < RS * W; e += ADJ_FT) {
         const int c = e / W, d = e - c * W;
-        win[e] = (c < n) ? band_init(band4, tot, ib + c, d, M) : (d == 0 ? 1.0 : 0.0);
+        win[e] = A0(c, d);
     }
     // trailing elements of a panel step: window column t (0..bw-1, i.e. panel-relative column NB+t)
     // holds bw - t elements (row offsets o = 0 .. bw-t-1); linear index -> (t, o), decoded once.
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
     __syncthreads();
 
     int slot0 = 0;  // ring slot of column k
-    for (int k = 0; k < n; k += NB) {
+    for (int k = 0; k < ncols; k += NB) {
         // ---- (1) diagonal block, redundantly in every thread of the row waves (no barrier needed):
         //          m = chol(A[k..k+NB, k..k+NB]).  The other waves go straight to the barrier.
         double m[NB][NB], dinv[NB];
@@ -261,8 +303,7 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
         for (int e = tid; e < NB * W; e += ADJ_FT) {
             const int q = e / W, d = e - q * W;
             int sq = slot0 + q; if (sq >= RS) sq -= RS;
-            const int col = k + RS + q;
-            win[sq * W + d] = (col < n) ? band_init(band4, tot, ib + col, d, M) : (d == 0 ? 1.0 : 0.0);
+            win[sq * W + d] = A0(k + RS + q, d);
         }
         // ---- (3b) trailing update: A[j+o][j] -= sum_c lp[c][row] * lp[c][col]
         {
@@ -286,6 +327,65 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
         __syncthreads();
         slot0 += NB; if (slot0 >= RS) slot0 -= RS;
     }
+    if (twisted) {  // window columns ncols .. ncols+nm-1, rows inside the middle block
+        double* dd = dump + ((size_t)img * 2 + rev) * (size_t)(bw + ADJ_G) * (bw + ADJ_G);
+        const int nm = sp.nm;
+        for (int e = tid; e < nm * nm; e += ADJ_FT) {
+            const int q = e / nm, d = e - q * nm;
+            if (q + d < nm) {
+                int sq = slot0 + q; if (sq >= RS) sq -= RS;
+                dd[q * nm + d] = (d <= bw) ? win[sq * W + d] : 0.0;
+            }
+        }
+    }
+}
+
+// Dense Cholesky of the middle block of the twisted factorisation: D = (top window) + (bottom
+// window, index-reversed) - A, nm x nm with bw <= nm < bw + NB, one workgroup per image, D in LDS.
+// Lm: [O][nm*nm] row-major lower triangle.
+__global__ __launch_bounds__(256) void adj_mid_factor_kernel(const double* __restrict__ band4,
+                                                             const double* __restrict__ dump, int M, int N,
+                                                             int O, double* __restrict__ Lm,
+                                                             int* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bw = M, n = M * N;
+    const AdjSplit sp = adj_split(n, bw);
+    const int nm = sp.nm, ld = nm + 1;
+    double* D = smem;  // [nm][ld]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const size_t tot = (size_t)n * O, ib = (size_t)img * n;
+    const double* dt = dump + ((size_t)img * 2) * (size_t)(bw + ADJ_G) * (bw + ADJ_G);
+    const double* db = dt + (size_t)(bw + ADJ_G) * (bw + ADJ_G);
+    for (int e = tid; e < nm * nm; e += 256) {
+        const int r = e / nm, c = e - r * nm;
+        double v = 0.0;
+        if (r >= c) {
+            const int d = r - c;
+            v = dt[c * nm + d] + db[(nm - 1 - r) * nm + d] - ((d <= bw) ? band_init(band4, tot, ib + sp.m + c, d, M) : 0.0);
+        }
+        D[r * ld + c] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < nm; ++k) {
+        const double piv = D[k * ld + k];
+        if (!(piv > 0.0) && tid == 0) fail[img] = sp.m + k + 1;
+        double d, di;
+        sqrt_rsqrt(piv, d, di);
+        __syncthreads();
+        for (int r = k + tid; r < nm; r += 256) D[r * ld + k] = (r == k) ? d : D[r * ld + k] * di;
+        __syncthreads();
+        const int rem = nm - 1 - k;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int r = k + 1 + e / rem, c = k + 1 + e % rem;
+            if (r >= c) D[r * ld + c] -= D[r * ld + k] * D[c * ld + k];
+        }
+        __syncthreads();
+    }
+    double* out = Lm + (size_t)img * (bw + ADJ_G) * (bw + ADJ_G);
+    for (int e = tid; e < nm * nm; e += 256) {
+        const int r = e / nm, c = e - r * nm;
+        out[e] = (r >= c) ? D[r * ld + c] : 0.0;
+    }
 }
 
 // Inverses of the 64x64 diagonal blocks of L, so that the block substitutions of the solve become
@@ -296,15 +396,17 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
 //   invB[(r*64 + c)] = X[r][c]  (lane c reads column c, coalesced over c)  -> backward x = X^T z
 // Rows/columns beyond n are padded with the identity.
 constexpr int SB = 64;
-__global__ __launch_bounds__(64) void adj_invdiag_kernel(const double* __restrict__ L, int M, int N,
+__global__ __launch_bounds__(64) void adj_invdiag_kernel(const double* __restrict__ L, int M, int N, int ncols,
                                                          double* __restrict__ invF, double* __restrict__ invB) {
     __shared__ double tri[SB * (SB + 1)];  // L_bb element (r, c) at r*65 + c
     __shared__ double X[SB * (SB + 1)];    // X element (r, j) at r*65 + j
-    const int W = M + 1, bw = M, n = M * N;
-    const int nblk = (n + SB - 1) / SB;
+    const int W = M + 1, bw = M, ntot = M * N;
+    const int n = ncols;  // columns of this factor (the whole matrix, or one side of the twisted split)
+    const int nblk = (ntot + SB - 1) / SB;
     const int bi = blockIdx.x, img = blockIdx.y;
     const int k0 = bi * SB, lane = threadIdx.x;
-    const double* Li = L + (size_t)img * n * W;
+    if (k0 >= n) return;
+    const double* Li = L + (size_t)img * ntot * W;
     for (int c = 0; c < SB; ++c) {  // column c of the block: rows r = lane, coalesced
         const int r = lane;
         double v = (r == c) ? 1.0 : 0.0;
@@ -456,6 +558,171 @@ __global__ __launch_bounds__(256) void adj_solve_kernel(const double* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Twisted (two-sided) variant of the solve: two workgroups per image.  Side 0 works on columns
+// [0, m) of A in natural order, side 1 on the first nbot columns of the index-reversed matrix; both
+// column counts are multiples of 64.  PHASE 0: forward substitution of the side, the updated
+// right-hand side of the nm middle rows is left in `spill`.  PHASE 1: backward substitution of the
+// side, starting from the already solved middle rows.  adj_mid_solve_kernel sits in between.
+// ------------------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(256) void adj_solve_tw_kernel(const double* __restrict__ L0, const double* __restrict__ L1,
+                                                           const double* __restrict__ invF, const double* __restrict__ invB,
+                                                           int M, int N, double* __restrict__ x,
+                                                           double* __restrict__ acc, double* __restrict__ spill) {
+    __shared__ double ring[RING];
+    __shared__ double xs[SB];
+    __shared__ double ps[SB][4];
+    const int W = M + 1, bw = M, n = M * N;
+    const AdjSplit sp = adj_split(n, bw);
+    const int img = blockIdx.x, rev = blockIdx.y;
+    const int ncol = rev ? sp.nbot : sp.m, nrow = ncol + sp.nm;
+    const size_t ib = (size_t)img * n;
+    const double* Li = (rev ? L1 : L0) + ib * W;
+    const int nblk_tot = (n + SB - 1) / SB;
+    const size_t ioff = ((size_t)rev * gridDim.x + img) * nblk_tot * SB * SB;
+    const double* iF = invF + ioff;
+    const double* iB = invB + ioff;
+    double* xv = x + ib;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = ncol / SB;
+    auto XI = [&](int k) -> int { return rev ? n - 1 - k : k; };  // side-local row -> global row
+    double* sp_out = spill + ((size_t)img * 2 + rev) * RING;
+
+    if (PHASE == 0) {
+        ring[tid] = (tid < nrow) ? xv[XI(tid)] : 0.0;
+        __syncthreads();
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int k0 = bi * SB;
+            const int rend = (k0 + SB - 1 + bw < nrow - 1) ? (k0 + SB - 1 + bw) : (nrow - 1);
+            double pre[SB];
+            const int urow = k0 + SB + (tid - 64);
+            if (wv == 0) {
+                double xr[SB];
+                const double* blk = iF + (size_t)bi * SB * SB;
+#pragma unroll
+                for (int c = 0; c < SB; ++c) xr[c] = blk[c * SB + lane];
+                const double bv = ring[(k0 + lane) & (RING - 1)];
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < SB; c += 4) {
+                    a0 = __builtin_fma(xr[c], readlane_f64(bv, c), a0);
+                    a1 = __builtin_fma(xr[c + 1], readlane_f64(bv, c + 1), a1);
+                    a2 = __builtin_fma(xr[c + 2], readlane_f64(bv, c + 2), a2);
+                    a3 = __builtin_fma(xr[c + 3], readlane_f64(bv, c + 3), a3);
+                }
+                const double val = (a0 + a1) + (a2 + a3);
+                xs[lane] = val;
+                xv[XI(k0 + lane)] = val;
+            } else {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) {
+                    const int d = urow - (k0 + c);
+                    pre[c] = (urow <= rend && d <= bw) ? Li[(size_t)(k0 + c) * W + d] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {
+                const int rnew = k0 + RING + lane;
+                ring[(k0 + lane) & (RING - 1)] = (rnew < nrow) ? xv[XI(rnew)] : 0.0;
+            } else if (urow <= rend) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < SB; c += 2) {
+                    s0 = __builtin_fma(pre[c], xs[c], s0);
+                    s1 = __builtin_fma(pre[c + 1], xs[c + 1], s1);
+                }
+                ring[urow & (RING - 1)] -= s0 + s1;
+            }
+            __syncthreads();
+        }
+        if (tid < sp.nm) sp_out[tid] = ring[(ncol + tid) & (RING - 1)];  // b_mid - (this side's updates)
+    } else {
+        if (tid < sp.nm) ring[(ncol + tid) & (RING - 1)] = xv[XI(ncol + tid)];  // solved middle rows
+        __syncthreads();
+        for (int bi = nblk - 1; bi >= 0; --bi) {
+            const int k0 = bi * SB;
+            double xc[SB];
+            if (wv == 0) {
+                const double* blk = iB + (size_t)bi * SB * SB;
+#pragma unroll
+                for (int r = 0; r < SB; ++r) xc[r] = blk[r * SB + lane];
+            }
+            {
+                const int c = tid >> 2, part = tid & 3;
+                const int kc = k0 + c;
+                const int dlo = k0 + SB - kc;
+                const int dhi = (nrow - 1 - kc < bw) ? (nrow - 1 - kc) : bw;
+                double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int d0 = dlo + part; d0 <= dhi; d0 += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int d = d0 + 4 * u;
+                        if (d <= dhi) a8[u] = __builtin_fma(Li[(size_t)kc * W + d], ring[(kc + d) & (RING - 1)], a8[u]);
+                    }
+                }
+                ps[c][part] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+            }
+            __syncthreads();
+            if (wv == 0) {
+                const double zv = xv[XI(k0 + lane)] - (((ps[lane][0] + ps[lane][1]) + ps[lane][2]) + ps[lane][3]);
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int r = 0; r < SB; r += 4) {
+                    a0 = __builtin_fma(xc[r], readlane_f64(zv, r), a0);
+                    a1 = __builtin_fma(xc[r + 1], readlane_f64(zv, r + 1), a1);
+                    a2 = __builtin_fma(xc[r + 2], readlane_f64(zv, r + 2), a2);
+                    a3 = __builtin_fma(xc[r + 3], readlane_f64(zv, r + 3), a3);
+                }
+                const double val = (a0 + a1) + (a2 + a3);
+                ring[(k0 + lane) & (RING - 1)] = val;
+                if (acc) acc[ib + XI(k0 + lane)] += val;
+                xv[XI(k0 + lane)] = val;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Middle block of the twisted solve: rhs = (top spill) + (bottom spill, reversed) - b_mid, dense
+// forward and backward substitution with Lm (nm x nm, staged in LDS), result to x[m .. m+nm).
+__global__ __launch_bounds__(256) void adj_mid_solve_kernel(const double* __restrict__ Lm, int M, int N,
+                                                            double* __restrict__ x, double* __restrict__ acc,
+                                                            const double* __restrict__ spill) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bw = M, n = M * N;
+    const AdjSplit sp = adj_split(n, bw);
+    const int nm = sp.nm, ld = nm + 1;
+    double* D = smem;            // [nm][ld]
+    double* v = smem + nm * ld;  // [nm]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const size_t ib = (size_t)img * n;
+    const double* Lg = Lm + (size_t)img * (bw + ADJ_G) * (bw + ADJ_G);
+    const double* st = spill + ((size_t)img * 2) * RING;
+    const double* sb = st + RING;
+    for (int e = tid; e < nm * nm; e += 256) D[(e / nm) * ld + (e % nm)] = Lg[e];
+    for (int r = tid; r < nm; r += 256) v[r] = st[r] + sb[nm - 1 - r] - x[ib + sp.m + r];
+    __syncthreads();
+    for (int k = 0; k < nm; ++k) {  // forward, column oriented
+        const double xk = v[k] / D[k * ld + k];
+        __syncthreads();
+        if (tid == 0) v[k] = xk;
+        for (int r = k + 1 + tid; r < nm; r += 256) v[r] -= D[r * ld + k] * xk;
+        __syncthreads();
+    }
+    for (int k = nm - 1; k >= 0; --k) {  // backward: L^T, uses row k of L
+        const double xk = v[k] / D[k * ld + k];
+        __syncthreads();
+        if (tid == 0) v[k] = xk;
+        for (int c = tid; c < k; c += 256) v[c] -= D[k * ld + c] * xk;
+        __syncthreads();
+    }
+    for (int r = tid; r < nm; r += 256) {
+        x[ib + sp.m + r] = v[r];
+        if (acc) acc[ib + sp.m + r] += v[r];
+    }
+}
+
 // out = rhs - (I + S G^T W G S) p   (matrix free; the flux of the three pixels that touch a node
 // is recomputed instead of being staged, so one pass and no atomics).
 __device__ __forceinline__ void adj_flux(const AdjCoef& C, const double* __restrict__ p, size_t q, int i,
@@ -510,27 +777,26 @@ __global__ __launch_bounds__(256) void adj_gradpix_kernel(AdjCoef C, const doubl
     }
 }
 
-// calc_adjoint(PatchOp, .) summed over images: out[pa + am*pb] = sum over the patch's pixels and
-// all O images.  One workgroup per patch; fixed order -> reproducible.
+// calc_adjoint(PatchOp, .): partial[(pa + am*pb)*O + k] = sum of image k's pixel contributions over
+// the patch.  grid (am*an, O); sum_final_kernel then adds the O images of each patch in image order
+// (fixed order -> bitwise reproducible, and every image/patch pair gets its own workgroup).
 __global__ __launch_bounds__(256) void patch_sum_kernel(const double* __restrict__ gpix, int M, int N, int O,
-                                                        int am, int an, double* __restrict__ out) {
+                                                        int am, int an, double* __restrict__ partial) {
     __shared__ double sh[4];
-    const int pa = blockIdx.x % am, pb = blockIdx.x / am;
+    const int pa = blockIdx.x % am, pb = blockIdx.x / am, k = blockIdx.y;
     // pixels i with (i*am)/M == pa  <=>  i in [ceil(pa*M/am), ceil((pa+1)*M/am))
     const int i0 = (int)(((long)pa * M + am - 1) / am), i1 = (int)(((long)(pa + 1) * M + am - 1) / am);
     const int j0 = (int)(((long)pb * N + an - 1) / an), j1 = (int)(((long)(pb + 1) * N + an - 1) / an);
     const int wi = i1 - i0, wj = j1 - j0;
-    const long cnt = (long)wi * wj * O;
+    const int cnt = wi * wj;
+    const double* g = gpix + (size_t)k * M * N;
     double s = 0.0;
-    for (long e = threadIdx.x; e < cnt; e += 256) {
-        const int i = i0 + (int)(e % wi);
-        const long r = e / wi;
-        const int j = j0 + (int)(r % wj);
-        const int k = (int)(r / wj);
-        s += gpix[(size_t)k * M * N + i + (size_t)M * j];
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int i = i0 + e % wi, j = j0 + e / wi;
+        s += g[i + (size_t)M * j];
     }
     s = block_sum<256>(s, sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * O + k] = s;
 }
 
 // ||r||^2 and ||rhs||^2 per image for the residual statistic: partial[k*2 + {0,1}].

@@ -113,7 +113,9 @@ struct bpltv_handle {
     double* d_coef = nullptr;   // 8 planes
     double* d_band4 = nullptr;  // 4 planes
     double* d_L = nullptr;
-    double *d_invF = nullptr, *d_invB = nullptr;  // inverted 64x64 diagonal blocks of L, two layouts
+    double *d_invF = nullptr, *d_invB = nullptr;  // inverted 64x64 diagonal blocks of L, two layouts (x2 sides)
+    double *d_L1 = nullptr, *d_dump = nullptr, *d_Lm = nullptr, *d_spill = nullptr;  // twisted factorisation
+    bool adj_twisted = false;
     double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
     double* d_resn = nullptr;
     int* d_fail = nullptr;
@@ -527,8 +529,25 @@ int adj_alloc(bpltv_t* h) {
     HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
     {
         const size_t nblk = (h->npx + SB - 1) / SB;
-        HIPCHK(h, hipMalloc((void**)&h->d_invF, (size_t)h->O * nblk * SB * SB * sizeof(double)));
-        HIPCHK(h, hipMalloc((void**)&h->d_invB, (size_t)h->O * nblk * SB * SB * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_invB, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
+    }
+    {   // two-sided (twisted) factorisation: two workgroups per image meet in a dense middle block
+        const AdjSplit sp = adj_split((int)h->npx, h->M);
+        const size_t midb = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
+        h->adj_twisted = sp.m >= ADJ_G && sp.nbot >= ADJ_G && sp.nm <= 140 && midb <= 160 * 1024 &&
+                         sp.nm >= h->M && (size_t)sp.nm <= (size_t)h->M + 4;
+        if (h->adj_twisted) {
+            const size_t blk = (size_t)(h->M + ADJ_G) * (h->M + ADJ_G);
+            HIPCHK(h, hipMalloc((void**)&h->d_L1, tot * W * sizeof(double)));
+            HIPCHK(h, hipMalloc((void**)&h->d_dump, 2 * (size_t)h->O * blk * sizeof(double)));
+            HIPCHK(h, hipMalloc((void**)&h->d_Lm, (size_t)h->O * blk * sizeof(double)));
+            HIPCHK(h, hipMalloc((void**)&h->d_spill, 2 * (size_t)h->O * RING * sizeof(double)));
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_mid_factor_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_mid_solve_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
     }
     HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
@@ -568,30 +587,61 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                        O, patch, reg, kact, C);
     hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
+    const int tw = h->adj_twisted ? 1 : 0;
+    const dim3 fgrid(O, tw ? 2 : 1);
     if (M == 128)  // the size of every shipped dataset: addressing folded at compile time
-        hipLaunchKernelGGL((adj_factor_kernel<8, 128>), dim3(O), dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_fail);
+        hipLaunchKernelGGL((adj_factor_kernel<8, 128>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
     else if (adj_factor_lds(M, 8) <= 160 * 1024)
-        hipLaunchKernelGGL((adj_factor_kernel<8, 0>), dim3(O), dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_fail);
+        hipLaunchKernelGGL((adj_factor_kernel<8, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
     else
-        hipLaunchKernelGGL((adj_factor_kernel<4, 0>), dim3(O), dim3(ADJ_FT), adj_factor_lds(M, 4), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_fail);
-    hipLaunchKernelGGL(adj_invdiag_kernel, dim3((unsigned)((h->npx + SB - 1) / SB), O), dim3(64), 0, h->stream, h->d_L, M,
-                       N, h->d_invF, h->d_invB);
+        hipLaunchKernelGGL((adj_factor_kernel<4, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 4), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
+    const unsigned nblk_tot = (unsigned)((h->npx + SB - 1) / SB);
+    const AdjSplit sp = adj_split((int)h->npx, M);
+    const size_t mid_lds = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
+    double* invF1 = h->d_invF + (size_t)O * nblk_tot * SB * SB;
+    double* invB1 = h->d_invB + (size_t)O * nblk_tot * SB * SB;
+    if (tw) {
+        hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
+                           h->d_Lm, h->d_fail);
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L, M, N, sp.m, h->d_invF,
+                           h->d_invB);
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L1, M, N, sp.nbot, invF1,
+                           invB1);
+    } else {
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L, M, N, (int)h->npx,
+                           h->d_invF, h->d_invB);
+    }
+    auto solve = [&](double* vec, double* accv) {
+        if (tw) {
+            hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
+                               h->d_invB, M, N, vec, accv, h->d_spill);
+            hipLaunchKernelGGL(adj_mid_solve_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_Lm, M, N, vec, accv,
+                               h->d_spill);
+            hipLaunchKernelGGL(adj_solve_tw_kernel<1>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
+                               h->d_invB, M, N, vec, accv, h->d_spill);
+        } else {
+            hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, h->d_invF, h->d_invB, M, N, vec,
+                               accv);
+        }
+    };
     HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, h->d_invF, h->d_invB, M, N, h->d_p,
-                       (double*)nullptr);
+    solve(h->d_p, nullptr);
     for (int it = 0; it < nref; ++it) {
         hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
-        hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, h->d_invF, h->d_invB, M, N, h->d_r,
-                           h->d_p);
+        solve(h->d_r, h->d_p);
     }
     hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
     hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, (int)h->npx, h->d_resn);
     hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
                        h->d_gpix);
-    hipLaunchKernelGGL(patch_sum_kernel, dim3(am * an), dim3(256), 0, h->stream, h->d_gpix, M, N, O, am, an, d_out);
+    rc = ensure(h, &h->d_red, &h->red_cap, (size_t)am * an * O);
+    if (rc) return rc;
+    hipLaunchKernelGGL(patch_sum_kernel, dim3(am * an, O), dim3(256), 0, h->stream, h->d_gpix, M, N, O, am, an, h->d_red);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, O, am * an, 1.0, d_out,
+                       (double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     std::vector<int> fail(O);
@@ -755,7 +805,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_L, h->d_invF, h->d_invB, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)
