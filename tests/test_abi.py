@@ -96,3 +96,17 @@ def test_product_path_does_not_import_oracle():
                     if s.startswith(("#", "//", "*", '"""')) or "oracle/" in s and ("//" in s or "#" in s):
                         continue
                     assert "import oracle" not in s and "from oracle" not in s and "bplo_" not in s, (f, s)
+
+
+def test_plain_c_program_links_against_the_abi(tmp_path):
+    """examples/c_abi_demo.c (plain C11, no Python, no torch) compiles against include/bpltv.h and
+    links against libbpltv.so -- what a Julia ccall or any other FFI sees."""
+    import subprocess
+    from bpldenoising_amd import _lib
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", str(exe), "-L", libdir, "-lbpltv",
+           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lm"]
+    subprocess.check_call(cmd)
+    assert exe.exists()

@@ -219,3 +219,88 @@ def test_sharded_learning_function_rccl_single_rank(gpu_solver_cls, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_plain_c_demo_runs(gpu_solver_cls, tmp_path):
+    """The C demo of the ABI runs on the GPU without Python in the loop."""
+    import os, subprocess
+    from conftest import ROOT
+    from bpldenoising_amd import _lib
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"),
+                           "-o", str(exe), "-L", libdir, "-lbpltv", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lm"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "scalar alpha" in out.stdout and "cost curve" in out.stdout
+    cost = float(out.stdout.split("cost ")[1].split()[0])
+    assert 0 < cost < 1e4
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_configurations(gpu_solver_cls, oracle, seed):
+    """Random shapes / parameters / iteration counts: u bit-exact, cost and gradient within tolerance."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(4):
+        O = int(rng.integers(1, 4)); M = int(rng.integers(2, 120)); N = int(rng.integers(2, 120))
+        ub, f = synth_batch(O, N, M, seed=int(rng.integers(1 << 30)))
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            alpha = float(rng.uniform(0.01, 0.3))
+        elif mode == 1:
+            alpha = rng.uniform(0.02, 0.3, size=(int(rng.integers(1, min(4, N) + 1)), int(rng.integers(1, min(4, M) + 1))))
+        else:
+            alpha = rng.uniform(0.02, 0.3, size=(N, M))
+        kw = dict(maxiter=int(rng.integers(0, 260)), accel=bool(rng.integers(0, 2)), rho=float(rng.choice([0.0, 0.0, 0.02])),
+                  tau0=float(rng.uniform(2, 6)), sigma0=float(rng.uniform(0.1, 0.19)))
+        s = gpu_solver_cls(M, N, O)
+        s.set_data(ub, f)
+        u = s.denoise(alpha, tile_iters=int(rng.integers(0, 9)), **kw)
+        u0 = oracle.pdhg(f, alpha, **kw)
+        assert np.array_equal(u, u0), (O, N, M, mode, kw)
+        if kw["maxiter"] >= 50 and mode != 2:
+            _, cost, grad = s.evaluate(alpha, 0.1, **kw)
+            assert np.isclose(cost, oracle.cost(u0, ub), rtol=1e-12)
+            assert np.allclose(grad, oracle.gradient(alpha, u0, ub), rtol=2e-6, atol=1e-9)
+        s.close()
+
+
+def _gpu_rank_worker(rank, world, port, q):
+    import os, sys
+    from conftest import ROOT, synth_batch as sb
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bpldenoising_amd import ShardedLearningFunction
+    ub, f = sb(5, 64, 64, seed=28)
+    fn = ShardedLearningFunction((ub, f))          # HIP solver per rank, all ranks on cuda:0
+    u, cost, grad = fn(np.array([[0.08, 0.12], [0.1, 0.05]]), 0.1, maxiter=300)
+    q.put((rank, fn.lo, fn.hi, u, cost, np.asarray(grad)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_sharded_evaluate_on_one_gpu(gpu_solver_cls, oracle):
+    """Two processes, each with its own libbpltv handle over its block of images (here both on the
+    one visible GPU), one all-reduce of [cost, grad] -- the N-GPU path with the device count of this box."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_gpu_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ub, f = synth_batch(5, 64, 64, seed=28)
+    P = np.array([[0.08, 0.12], [0.1, 0.05]])
+    u0 = oracle.pdhg(f, P, maxiter=300)
+    c0, g0 = oracle.cost(u0, ub), oracle.gradient(P, u0, ub)
+    for rank, lo, hi, u, cost, grad in res:
+        assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
+        assert np.array_equal(u, u0[lo:hi])
+        assert np.isclose(cost, c0, rtol=1e-13) and np.allclose(grad, g0, rtol=1e-6)
