@@ -54,6 +54,9 @@ const Variant kVariants[] = {
     VAR(2, 1, 64, 16),  // 8: 128x16 region
     VAR(2, 2, 64, 16),  // 9: 128x32 region
     VAR(1, 2, 32, 32),  // 10: 32x64 region
+    VAR(1, 2, 40, 20),  // 11: 40x40 region, 800 threads, 2 px/thread (core 24 at T = 8: 5x5 tiles per 128^2 image)
+    VAR(2, 2, 20, 20),  // 12: 40x40 region, 400 threads, 4 px/thread
+    VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

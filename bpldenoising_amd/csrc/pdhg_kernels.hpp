@@ -262,11 +262,12 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 xp1[pj][pi] = sxb[n1[pj][pi]];
                 xpM[pj][pi] = sxb[n2[pj][pi]];
             }
+        double n2v[PJ][PI];
+        bool any_out = false;
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const double b = xb[pj][pi];
                 const double d1 = xp1[pj][pi] - b;
                 const double d2 = xpM[pj][pi] - b;
@@ -278,16 +279,33 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                     y1n = y1n / den;
                     y2n = y2n / den;
                 }
-                const double n2 = __builtin_fma(y2n, y2n, y1n * y1n);
-                if (n2 > a * a) {
-                    const double v = a * rsqrt_nr(n2);
-                    y1n = y1n * v;
-                    y2n = y2n * v;
-                }
                 y1[pj][pi] = y1n;
                 y2[pj][pi] = y2n;
-                sy1[lj * S1 + li + 1] = y1n;
-                sy2[(lj + 1) * RI + li] = y2n;
+                n2v[pj][pi] = __builtin_fma(y2n, y2n, y1n * y1n);
+                any_out |= n2v[pj][pi] > a * a;
+            }
+        // projection onto the alpha-ball.  One pixel per thread: a wave whose pixels all lie inside
+        // skips the rsqrt.  Several pixels per thread: the rsqrt chains of the thread's pixels are
+        // issued together (independent, interleaved by the scheduler) and selected afterwards.
+        if (any_out) {
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+                for (int pi = 0; pi < PI; ++pi) {
+                    const double a = al[pj][pi];
+                    const double v = a * rsqrt_nr(n2v[pj][pi]);
+                    const bool outp = n2v[pj][pi] > a * a;
+                    y1[pj][pi] = outp ? y1[pj][pi] * v : y1[pj][pi];
+                    y2[pj][pi] = outp ? y2[pj][pi] * v : y2[pj][pi];
+                }
+        }
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj)
+#pragma unroll
+            for (int pi = 0; pi < PI; ++pi) {
+                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                sy1[lj * S1 + li + 1] = y1[pj][pi];
+                sy2[(lj + 1) * RI + li] = y2[pj][pi];
             }
         tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
         __syncthreads();

@@ -304,3 +304,20 @@ def test_two_rank_sharded_evaluate_on_one_gpu(gpu_solver_cls, oracle):
         assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
         assert np.array_equal(u, u0[lo:hi])
         assert np.isclose(cost, c0, rtol=1e-13) and np.allclose(grad, g0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 17])
+def test_adjoint_split_edge_cases(gpu_solver_cls, oracle, N):
+    """M = 128 with very few image columns: the two-sided factorisation degenerates (sides of 0, 64,
+    ... columns); results must not depend on which path runs."""
+    ub, f = synth_batch(2, N, 128, seed=60 + N)
+    s = gpu_solver_cls(128, N, 2)
+    s.set_data(ub, f)
+    for alpha in (0.1, np.array([[0.06, 0.15]])):
+        u, cost, grad = s.evaluate(alpha, 0.1, maxiter=400)
+        u0 = oracle.pdhg(f, alpha, maxiter=400)
+        assert np.array_equal(u, u0)
+        assert np.allclose(grad, oracle.gradient(alpha, u0, ub), rtol=2e-6, atol=1e-9)
+        _, _, greg = s.evaluate(alpha, 0.0, maxiter=400)
+        assert np.allclose(greg, oracle.gradient(alpha, u0, ub, reg=True), rtol=1e-7, atol=1e-11)
+    s.close()
