@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbpltv.so")
+LIB_PATH = os.environ.get("BPLTV_LIB_PATH", os.path.join(_HERE, "libbpltv.so"))  # override: A/B builds
 
 _dp = C.POINTER(C.c_double)
 
