@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/bpltv.h"
+#include "adjoint_hbm_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
 
@@ -119,6 +120,8 @@ struct bpltv_handle {
     double *d_invF = nullptr, *d_invB = nullptr;  // inverted 64x64 diagonal blocks of L, two layouts (x2 sides)
     double *d_L1 = nullptr, *d_dump = nullptr, *d_Lm = nullptr, *d_spill = nullptr;  // twisted factorisation
     bool adj_twisted = false;
+    bool adj_hbm = false;  // M too wide for the LDS window: band factored in place in HBM
+    double *d_band = nullptr, *d_l11 = nullptr;
     double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
     double* d_resn = nullptr;
     int* d_fail = nullptr;
@@ -523,14 +526,21 @@ int adj_alloc(bpltv_t* h) {
     if (h->adj_ready) return BPLTV_OK;
     const size_t tot = h->tot;
     const size_t W = (size_t)h->M + 1;
-    if (adj_factor_lds(h->M, 4) > 160 * 1024)
-        return set_err(h, BPLTV_E_UNSUPPORTED,
-                       "adjoint gradient: M = %d needs a %zu-byte LDS window (limit 163840); M <= 138 supported",
-                       h->M, adj_factor_lds(h->M, 4));
+    h->adj_hbm = adj_factor_lds(h->M, 4) > 160 * 1024;
     HIPCHK(h, hipMalloc((void**)&h->d_coef, 8 * tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_band4, 4 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
-    {
+    if (h->adj_hbm) {
+        size_t freeb = 0, totalb = 0;
+        (void)hipMemGetInfo(&freeb, &totalb);
+        const size_t need = tot * W * sizeof(double);
+        if (need + (2ull << 30) > freeb)
+            return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band of %d images of %dx%d needs %.1f GB of HBM (%.1f GB free)",
+                           h->O, h->M, h->N, need / 1e9, freeb / 1e9);
+        HIPCHK(h, hipMalloc((void**)&h->d_band, need));
+        HIPCHK(h, hipMalloc((void**)&h->d_l11, (size_t)h->O * HB_NB * HB_NB * sizeof(double)));
+    }
+    if (!h->adj_hbm) HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
+    if (!h->adj_hbm) {
         const size_t nblk = (h->npx + SB - 1) / SB;
         HIPCHK(h, hipMalloc((void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
         HIPCHK(h, hipMalloc((void**)&h->d_invB, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
@@ -538,7 +548,7 @@ int adj_alloc(bpltv_t* h) {
     {   // two-sided (twisted) factorisation: two workgroups per image meet in a dense middle block
         const AdjSplit sp = adj_split((int)h->npx, h->M);
         const size_t midb = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
-        h->adj_twisted = sp.m >= ADJ_G && sp.nbot >= ADJ_G && sp.nm <= 140 && midb <= 160 * 1024 &&
+        h->adj_twisted = !h->adj_hbm && sp.m >= ADJ_G && sp.nbot >= ADJ_G && sp.nm <= 140 && midb <= 160 * 1024 &&
                          sp.nm >= h->M && (size_t)sp.nm <= (size_t)h->M + 4;
         if (h->adj_twisted) {
             const size_t blk = (size_t)(h->M + ADJ_G) * (h->M + ADJ_G);
@@ -557,6 +567,7 @@ int adj_alloc(bpltv_t* h) {
     HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_resn, 2 * (size_t)h->O * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
+    if (!h->adj_hbm)
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 128>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 0>),
@@ -590,9 +601,26 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                        O, patch, reg, kact, C);
     hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
+    if (h->adj_hbm) {
+        const size_t W = (size_t)M + 1;
+        const size_t nel = tot * W;
+        hipLaunchKernelGGL(hb_init_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, h->d_band4, M, N, O,
+                           h->d_band);
+        const int n = (int)h->npx;
+        const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2;
+        const unsigned prow = (unsigned)((M + HB_NB + HB_ROWS - 1) / HB_ROWS);
+        for (int k0 = 0; k0 < n; k0 += HB_NB) {
+            hipLaunchKernelGGL(hb_panel_kernel, dim3(prow, O), dim3(HB_ROWS), 0, h->stream, h->d_band, M, N, k0, h->d_l11,
+                               h->d_fail);
+            hipLaunchKernelGGL(hb_update_kernel, dim3(ntile, O), dim3(256), 0, h->stream, h->d_band, M, N, k0, h->d_l11);
+        }
+        HIPCHK(h, hipGetLastError());
+    }
     const int tw = h->adj_twisted ? 1 : 0;
     const dim3 fgrid(O, tw ? 2 : 1);
-    if (M == 128)  // the size of every shipped dataset: addressing folded at compile time
+    if (h->adj_hbm) {
+        // factor done above
+    } else if (M == 128)  // the size of every shipped dataset: addressing folded at compile time
         hipLaunchKernelGGL((adj_factor_kernel<8, 128>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
                            h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
     else if (adj_factor_lds(M, 8) <= 160 * 1024)
@@ -606,7 +634,8 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     const size_t mid_lds = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
     double* invF1 = h->d_invF + (size_t)O * nblk_tot * SB * SB;
     double* invB1 = h->d_invB + (size_t)O * nblk_tot * SB * SB;
-    if (tw) {
+    if (h->adj_hbm) {
+    } else if (tw) {
         hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
                            h->d_Lm, h->d_fail);
         hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L, M, N, sp.m, h->d_invF,
@@ -618,7 +647,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                            h->d_invF, h->d_invB);
     }
     auto solve = [&](double* vec, double* accv) {
-        if (tw) {
+        if (h->adj_hbm) {
+            hipLaunchKernelGGL(hb_solve_kernel, dim3(O), dim3(1024), 0, h->stream, h->d_band, M, N, vec, accv);
+        } else if (tw) {
             hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
                                h->d_invB, M, N, vec, accv, h->d_spill);
             hipLaunchKernelGGL(adj_mid_solve_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_Lm, M, N, vec, accv,
@@ -640,11 +671,17 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, (int)h->npx, h->d_resn);
     hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
                        h->d_gpix);
-    rc = ensure(h, &h->d_red, &h->red_cap, (size_t)am * an * O);
-    if (rc) return rc;
-    hipLaunchKernelGGL(patch_sum_kernel, dim3(am * an, O), dim3(256), 0, h->stream, h->d_gpix, M, N, O, am, an, h->d_red);
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, O, am * an, 1.0, d_out,
-                       (double*)nullptr);
+    if (am == M && an == N && !(M == 1 && N == 1)) {  // pixelwise parameter map: plain sum over images
+        hipLaunchKernelGGL(map_sum_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, h->stream, h->d_gpix, h->npx, O,
+                           d_out);
+    } else {
+        rc = ensure(h, &h->d_red, &h->red_cap, (size_t)am * an * O);
+        if (rc) return rc;
+        hipLaunchKernelGGL(patch_sum_kernel, dim3(am * an, O), dim3(256), 0, h->stream, h->d_gpix, M, N, O, am, an,
+                           h->d_red);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, O, am * an, 1.0, d_out,
+                           (double*)nullptr);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     std::vector<int> fail(O);
@@ -808,7 +845,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)

@@ -43,6 +43,9 @@ enum {
     BPLTV_E_NOMEM = 5,
     BPLTV_E_UNSUPPORTED = 6
 };
+/* Sizes: PDHG, loss, sweep and the adjoint gradient accept any M x N x O that fits in HBM.  The gradient
+ * uses an LDS-resident band window for M <= 138 and an HBM-resident band (M*N*(M+1) doubles per image,
+ * allocated on first use) beyond that. */
 
 typedef struct bpltv_handle bpltv_t;
 

@@ -133,13 +133,31 @@ def test_error_behaviour(gpu_solver_cls):
         s.set_data(ub[:, :16], f)
     assert s.denoise(0.1, maxiter=10).shape == (1, 32, 32)   # handle still usable after errors
     s.close()
-    big = gpu_solver_cls(200, 64, 1)                   # adjoint window limited to M <= 141
-    ub, f = synth_batch(1, 64, 200, seed=25)
-    big.set_data(ub, f)
-    with pytest.raises(BpltvError) as e:
-        big.evaluate(0.1, 0.1, maxiter=10)
-    assert e.value.code == 6
-    big.close()
+
+
+@pytest.mark.parametrize("shape,alpha", [((2, 40, 200), 0.1), ((1, 70, 150), np.array([[0.06, 0.15], [0.1, 0.2]])),
+                                         ((1, 36, 160), "map")], ids=["scalar200", "patch150", "map160"])
+def test_wide_images_use_the_hbm_band_path(gpu_solver_cls, oracle, shape, alpha):
+    """M > 138 does not fit the LDS window: the band is factored in place in HBM (one launch pair
+    per panel).  Same reduced system, same tolerance against the oracle."""
+    O, N, M = shape
+    ub, f = synth_batch(O, N, M, seed=70 + M)
+    if isinstance(alpha, str):
+        alpha = 0.05 + 0.1 * np.random.default_rng(4).random((N, M))
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u, cost, grad = s.evaluate(alpha, 0.1, maxiter=500)
+    u0 = oracle.pdhg(f, alpha, maxiter=500)
+    g0 = oracle.gradient(alpha, u0, ub)
+    assert np.array_equal(u, u0)
+    if np.ndim(g0) == 2 and g0.shape == (N, M):
+        assert np.allclose(grad, g0, rtol=1e-4, atol=2e-6 * np.abs(g0).max()) and np.isclose(grad.sum(), g0.sum(), rtol=1e-6)
+    else:
+        assert np.allclose(grad, g0, rtol=2e-6, atol=1e-9)
+    _, _, greg = s.evaluate(alpha, 0.0, maxiter=500)
+    gr0 = oracle.gradient(alpha, u0, ub, reg=True)
+    assert np.allclose(greg, gr0, rtol=1e-6, atol=1e-8 * np.abs(gr0).max())
+    s.close()
 
 
 def test_reference_named_entry_points(oracle):
