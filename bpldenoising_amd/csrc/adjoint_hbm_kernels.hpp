@@ -16,16 +16,19 @@ namespace bpltv {
 constexpr int HB_NB = 32;   // panel width
 constexpr int HB_ROWS = 256; // rows of the panel handled by one workgroup of hb_panel_kernel
 
-// band <- assembled matrix (4 diagonals), zero elsewhere
+// band <- assembled matrix (4 diagonals), zero elsewhere.  grid (nblocks, O), grid-stride over the
+// n*W entries of one image (a flat launch over all images would exceed 2^32 work-items at 8 x 1024^2).
 __global__ __launch_bounds__(256) void hb_init_kernel(const double* __restrict__ band4, int M, int N, int O,
                                                       double* __restrict__ band) {
     const int W = M + 1;
     const size_t n = (size_t)M * N, tot = n * O;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= tot * W) return;
-    const size_t col = e / W;  // global column index over images
-    const int d = (int)(e - col * W);
-    band[e] = band_init(band4, tot, col, d, M);
+    const size_t ib = (size_t)blockIdx.y * n;
+    const size_t cnt = n * W, stride = (size_t)gridDim.x * 256;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += stride) {
+        const size_t col = e / W;
+        const int d = (int)(e - col * W);
+        band[ib * W + e] = band_init(band4, tot, ib + col, d, M);
+    }
 }
 
 // Factor the HB_NB x HB_NB diagonal block at column k0 (redundantly in every workgroup, in wave 0
@@ -83,16 +86,33 @@ __global__ __launch_bounds__(HB_ROWS) void hb_panel_kernel(double* __restrict__ 
             for (int c = 0; c < HB_NB; ++c) l11buf[((size_t)img * HB_NB + rr) * HB_NB + c] = T[rr][c];
         return;
     }
-    // forward substitution of this row against L11; the row's entries live in LDS (dynamic loops,
-    // no register arrays): LP[tid][c]
+    // forward substitution of this row against L11.  The row's 32 entries are fetched first (all
+    // loads in flight together, coalesced across rows) into LDS, then substituted in place with
+    // dynamic loops (no register arrays), then stored.
     double* lrow = &LP[tid][0];
+#pragma unroll
     for (int c = 0; c < HB_NB; ++c) {
         const int d = rr - c;
-        double v = (c < nb && d <= bw) ? Bi[(size_t)(k0 + c) * W + d] : 0.0;
-        for (int q = 0; q < c; ++q) v = __builtin_fma(-lrow[q], T[c][q], v);
-        v *= Dinv[c];
-        lrow[c] = v;
-        if (c < nb && d <= bw) Bi[(size_t)(k0 + c) * W + d] = v;
+        lrow[c] = (c < nb && d <= bw) ? Bi[(size_t)(k0 + c) * W + d] : 0.0;
+    }
+    for (int c = 0; c < HB_NB; ++c) {
+        // four partial sums + unrolling keep the LDS reads pipelined (a rolled loop waits ~100
+        // cycles per read: 512 reads = 20 us per panel)
+        double v0 = lrow[c], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= c; q += 4) {
+            v0 = __builtin_fma(-lrow[q], T[c][q], v0);
+            v1 = __builtin_fma(-lrow[q + 1], T[c][q + 1], v1);
+            v2 = __builtin_fma(-lrow[q + 2], T[c][q + 2], v2);
+            v3 = __builtin_fma(-lrow[q + 3], T[c][q + 3], v3);
+        }
+        for (; q < c; ++q) v0 = __builtin_fma(-lrow[q], T[c][q], v0);
+        lrow[c] = ((v0 + v1) + (v2 + v3)) * Dinv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < HB_NB; ++c) {
+        const int d = rr - c;
+        if (c < nb && d <= bw) Bi[(size_t)(k0 + c) * W + d] = lrow[c];
     }
 }
 
@@ -153,92 +173,94 @@ __global__ __launch_bounds__(256) void hb_update_kernel(double* __restrict__ ban
         }
 }
 
-// Solve L L^T x = b in place, L in the band array; one workgroup of 1024 threads per image, blocks
-// of HB_NB columns; x in global memory.  If acc != nullptr the solution is added to it.
-__global__ __launch_bounds__(1024) void hb_solve_kernel(const double* __restrict__ band, int M, int N,
-                                                        double* __restrict__ x, double* __restrict__ acc) {
-    __shared__ double xs[HB_NB];
-    __shared__ double part[HB_NB][33];
+// Substitutions with L in the band array.  A single workgroup streaming the 8.6 GB factor of a
+// 1024^2 image is limited to one CU's memory bandwidth (~24 GB/s), so the work of every 64-column
+// block is spread over 1 + ceil(bw/64) one-wave workgroups and the kernel boundary is again the
+// grid-wide synchronisation: one launch per block.  Every workgroup recomputes the block's solution
+// (64x64 matrix-vector product with the inverted diagonal block of adj_invdiag_kernel, operands
+// broadcast by v_readlane); workgroup 0 stores it, workgroup 1+j applies it to its 64 rows.
+// Forward (L y = b):   in/out `x` = running right-hand side, solution rows -> `y`.
+// Backward (L^T x = y): in/out `y` = running right-hand side, solution rows -> `x` (and += acc).
+__device__ __forceinline__ double hb_block_matvec(const double* __restrict__ blk, double v, int lane) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        double xr[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xr[c] = blk[(hh * 32 + c) * SB + lane];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            a0 = __builtin_fma(xr[c], readlane_f64(v, hh * 32 + c), a0);
+            a1 = __builtin_fma(xr[c + 1], readlane_f64(v, hh * 32 + c + 1), a1);
+            a2 = __builtin_fma(xr[c + 2], readlane_f64(v, hh * 32 + c + 2), a2);
+            a3 = __builtin_fma(xr[c + 3], readlane_f64(v, hh * 32 + c + 3), a3);
+        }
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// grid (1 + ceil(bw/64), O), block 64
+__global__ __launch_bounds__(64) void hb_fwd_block_kernel(const double* __restrict__ band,
+                                                          const double* __restrict__ invF, int M, int N, int k0,
+                                                          double* __restrict__ x, double* __restrict__ y) {
     const int W = M + 1, bw = M, n = M * N;
-    const double* Bi = band + (size_t)blockIdx.x * n * W;
-    double* xv = x + (size_t)blockIdx.x * n;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nblk = (n + HB_NB - 1) / HB_NB;
-    // ---- forward
-    for (int bi = 0; bi < nblk; ++bi) {
-        const int k0 = bi * HB_NB;
-        const int nb = (n - k0 < HB_NB) ? (n - k0) : HB_NB;
-        if (tid < 64) {
-            // row `lane` of the 32x32 triangle and the reciprocal diagonal: all loads issued up
-            // front, the 32-step chain then runs on registers and readlane broadcasts only
-            double t[HB_NB];
-#pragma unroll
-            for (int c = 0; c < HB_NB; ++c)
-                t[c] = (c < lane && lane < nb) ? Bi[(size_t)(k0 + c) * W + (lane - c)] : 0.0;
-            const double di = (lane < nb) ? 1.0 / Bi[(size_t)(k0 + lane) * W] : 1.0;
-            double val = (lane < nb) ? xv[k0 + lane] : 0.0;
-#pragma unroll
-            for (int c = 0; c < HB_NB; ++c) {
-                const double v = readlane_f64(val, c) * readlane_f64(di, c);
-                if (lane == c) val = v;
-                if (lane > c) val = __builtin_fma(-t[c], v, val);
-            }
-            if (lane < nb) { xs[lane] = val; xv[k0 + lane] = val; }
-        }
-        __syncthreads();
-        const int rend = (k0 + nb - 1 + bw < n - 1) ? (k0 + nb - 1 + bw) : (n - 1);
-        for (int r = k0 + nb + tid; r <= rend; r += 1024) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < nb; ++c) {
-                const int d = r - (k0 + c);
-                if (d <= bw) s = __builtin_fma(Bi[(size_t)(k0 + c) * W + d], xs[c], s);
-            }
-            xv[r] -= s;
-        }
-        __syncthreads();
+    const int img = blockIdx.y, lane = threadIdx.x;
+    const double* Bi = band + (size_t)img * n * W;
+    double* xv = x + (size_t)img * n;
+    const int nblk = (n + SB - 1) / SB;
+    const double* blk = invF + ((size_t)img * nblk + k0 / SB) * SB * SB;
+    const double bv = (k0 + lane < n) ? xv[k0 + lane] : 0.0;
+    const double val = hb_block_matvec(blk, bv, lane);  // X[lane][:] . b_blk
+    if (blockIdx.x == 0) {
+        if (k0 + lane < n) y[(size_t)img * n + k0 + lane] = val;
+        return;
     }
-    // ---- backward
-    for (int bi = nblk - 1; bi >= 0; --bi) {
-        const int k0 = bi * HB_NB;
-        const int nb = (n - k0 < HB_NB) ? (n - k0) : HB_NB;
-        {   // tails: column c handled by 32 threads (tid / 32 = c)
-            const int c = tid >> 5, q = tid & 31;
-            double s = 0.0;
-            if (c < nb) {
-                const int kc = k0 + c;
-                const int dlo = k0 + nb - kc;
-                const int dhi = (n - 1 - kc < bw) ? (n - 1 - kc) : bw;
-                for (int d = dlo + q; d <= dhi; d += 32) s = __builtin_fma(Bi[(size_t)kc * W + d], xv[kc + d], s);
-            }
-            part[c][q] = s;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            double val = 0.0;
-            if (lane < nb) {
-                double s = 0.0;
-                for (int q = 0; q < 32; ++q) s += part[lane][q];
-                val = xv[k0 + lane] - s;
-            }
-            double t[HB_NB];  // column `lane` of the triangle: L[k0+cc][k0+lane], cc > lane
-#pragma unroll
-            for (int cc = 0; cc < HB_NB; ++cc)
-                t[cc] = (cc > lane && cc < nb && lane < nb) ? Bi[(size_t)(k0 + lane) * W + (cc - lane)] : 0.0;
-            const double di = (lane < nb) ? 1.0 / Bi[(size_t)(k0 + lane) * W] : 1.0;
-#pragma unroll
-            for (int c = HB_NB - 1; c >= 0; --c) {
-                const double v = readlane_f64(val, c) * readlane_f64(di, c);
-                if (lane == c) val = v;
-                if (lane < c) val = __builtin_fma(-t[c], v, val);
-            }
-            if (lane < nb) {
-                if (acc) acc[(size_t)blockIdx.x * n + k0 + lane] += val;
-                xv[k0 + lane] = val;
-            }
-        }
-        __syncthreads();
+    const int r = k0 + SB + (blockIdx.x - 1) * SB + lane;
+    if (r >= n || r > k0 + SB - 1 + bw) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < SB; c += 2) {
+        const int d0 = r - (k0 + c), d1 = d0 - 1;
+        const double l0 = (d0 <= bw && k0 + c < n) ? Bi[(size_t)(k0 + c) * W + d0] : 0.0;
+        const double l1 = (d1 <= bw && k0 + c + 1 < n) ? Bi[(size_t)(k0 + c + 1) * W + d1] : 0.0;
+        s0 = __builtin_fma(l0, readlane_f64(val, c), s0);
+        s1 = __builtin_fma(l1, readlane_f64(val, c + 1), s1);
     }
+    xv[r] -= s0 + s1;
+}
+
+__global__ __launch_bounds__(64) void hb_bwd_block_kernel(const double* __restrict__ band,
+                                                          const double* __restrict__ invB, int M, int N, int k0,
+                                                          double* __restrict__ y, double* __restrict__ x,
+                                                          double* __restrict__ acc) {
+    const int W = M + 1, bw = M, n = M * N;
+    const int img = blockIdx.y, lane = threadIdx.x;
+    const double* Bi = band + (size_t)img * n * W;
+    double* yv = y + (size_t)img * n;
+    const int nblk = (n + SB - 1) / SB;
+    const double* blk = invB + ((size_t)img * nblk + k0 / SB) * SB * SB;
+    const double zv = (k0 + lane < n) ? yv[k0 + lane] : 0.0;
+    const double val = hb_block_matvec(blk, zv, lane);  // X[:][lane] . z_blk
+    if (blockIdx.x == 0) {
+        if (k0 + lane < n) {
+            x[(size_t)img * n + k0 + lane] = val;
+            if (acc) acc[(size_t)img * n + k0 + lane] += val;
+        }
+        return;
+    }
+    // earlier equation k: y_k -= sum_c L[k0+c][k] x_{k0+c},  L[k0+c][k] = band[k][k0 + c - k]
+    const int k = k0 - 1 - ((blockIdx.x - 1) * SB + lane);
+    if (k < 0 || k0 - k > bw) return;
+    const double* col = Bi + (size_t)k * W + (k0 - k);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < SB; c += 2) {
+        const double l0 = (k0 - k + c <= bw && k0 + c < n) ? col[c] : 0.0;
+        const double l1 = (k0 - k + c + 1 <= bw && k0 + c + 1 < n) ? col[c + 1] : 0.0;
+        s0 = __builtin_fma(l0, readlane_f64(val, c), s0);
+        s1 = __builtin_fma(l1, readlane_f64(val, c + 1), s1);
+    }
+    yv[k] -= s0 + s1;
 }
 
 // pixelwise parameter map: out[q] = sum over images of gpix[k][q]

@@ -540,6 +540,11 @@ int adj_alloc(bpltv_t* h) {
         HIPCHK(h, hipMalloc((void**)&h->d_l11, (size_t)h->O * HB_NB * HB_NB * sizeof(double)));
     }
     if (!h->adj_hbm) HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
+    if (h->adj_hbm) {
+        const size_t nblk = (h->npx + SB - 1) / SB;
+        HIPCHK(h, hipMalloc((void**)&h->d_invF, (size_t)h->O * nblk * SB * SB * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_invB, (size_t)h->O * nblk * SB * SB * sizeof(double)));
+    }
     if (!h->adj_hbm) {
         const size_t nblk = (h->npx + SB - 1) / SB;
         HIPCHK(h, hipMalloc((void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
@@ -603,9 +608,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
     if (h->adj_hbm) {
         const size_t W = (size_t)M + 1;
-        const size_t nel = tot * W;
-        hipLaunchKernelGGL(hb_init_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, h->d_band4, M, N, O,
-                           h->d_band);
+        const size_t nel = h->npx * W;  // per image
+        const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
+        hipLaunchKernelGGL(hb_init_kernel, dim3(ib_blocks, O), dim3(256), 0, h->stream, h->d_band4, M, N, O, h->d_band);
         const int n = (int)h->npx;
         const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2;
         const unsigned prow = (unsigned)((M + HB_NB + HB_ROWS - 1) / HB_ROWS);
@@ -635,6 +640,8 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     double* invF1 = h->d_invF + (size_t)O * nblk_tot * SB * SB;
     double* invB1 = h->d_invB + (size_t)O * nblk_tot * SB * SB;
     if (h->adj_hbm) {
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_band, M, N, (int)h->npx,
+                           h->d_invF, h->d_invB);
     } else if (tw) {
         hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
                            h->d_Lm, h->d_fail);
@@ -648,7 +655,15 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     }
     auto solve = [&](double* vec, double* accv) {
         if (h->adj_hbm) {
-            hipLaunchKernelGGL(hb_solve_kernel, dim3(O), dim3(1024), 0, h->stream, h->d_band, M, N, vec, accv);
+            // one launch per 64-column block; d_gpix is free during the solves and holds y
+            const int n = (int)h->npx;
+            const unsigned chunks = 1 + (unsigned)((M + SB - 1) / SB);
+            for (int k0 = 0; k0 < n; k0 += SB)
+                hipLaunchKernelGGL(hb_fwd_block_kernel, dim3(chunks, O), dim3(64), 0, h->stream, h->d_band, h->d_invF, M, N, k0,
+                                   vec, h->d_gpix);
+            for (int k0 = ((n - 1) / SB) * SB; k0 >= 0; k0 -= SB)
+                hipLaunchKernelGGL(hb_bwd_block_kernel, dim3(chunks, O), dim3(64), 0, h->stream, h->d_band, h->d_invB, M, N, k0,
+                                   h->d_gpix, vec, accv);
         } else if (tw) {
             hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
                                h->d_invB, M, N, vec, accv, h->d_spill);
