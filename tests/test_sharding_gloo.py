@@ -6,7 +6,7 @@ import pytest
 from conftest import ROOT, synth_batch
 
 
-def _worker(rank, world, port, q, alpha):
+def _worker(rank, world, port, q, alpha, nimg=5):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -15,7 +15,7 @@ def _worker(rank, world, port, q, alpha):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bpldenoising_amd import ShardedLearningFunction
     from test_host_logic import FakeSolver
-    ub, f = synth_batch(5, 18, 14, seed=33)
+    ub, f = synth_batch(nimg, 18, 14, seed=33)
     fn = ShardedLearningFunction((ub, f), solver_factory=FakeSolver)
     u, cost, grad = fn(alpha, 0.1, maxiter=150)
     q.put((rank, fn.lo, fn.hi, None if u is None else u.copy(), cost, np.asarray(grad).copy()))
@@ -46,3 +46,27 @@ def test_gloo_sharded_evaluate(oracle, alpha, world):
         assert np.array_equal(u, u0[lo:hi])                        # each rank holds its block of u
         covered[lo:hi] = True
     assert covered.all()
+
+
+def test_more_ranks_than_images(oracle):
+    """cameraman-style datasets hold ONE image: ranks without images contribute zeros to the all-reduce
+    and still receive the batch totals."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 0.1, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ub, f = synth_batch(1, 18, 14, seed=33)
+    u0, c0, g0 = oracle.tv_op_learning_function(0.1, (ub, f), 0.1, maxiter=150)
+    for rank, lo, hi, u, cost, grad in res:
+        assert np.isclose(cost, c0, rtol=1e-14) and np.allclose(grad, g0, rtol=1e-12)
+        if rank == 0:
+            assert (lo, hi) == (0, 1) and np.array_equal(u, u0)
+        else:
+            assert lo == hi and u is None
