@@ -1,0 +1,869 @@
+// adjoint_bcr_kernels.hpp -- adjoint solve by block cyclic reduction (M <= 128).
+//
+// The reduced SPD system of adjoint_kernels.hpp is block tridiagonal: N diagonal blocks D_j (one image
+// column of M pixels each, tridiagonal) coupled by C_j = A[block j+1, block j] (bidiagonal).  A banded
+// Cholesky walks its M*N columns one after the other on one or two workgroups per image
+// (adj_factor_kernel); here the blocks are eliminated in odd-even (nested dissection) order instead:
+// level l (stride s = 2^l) eliminates the blocks j = s + 2s*t, all of them -- and all images -- at
+// once, leaving a block tridiagonal system on the blocks 2s*t.  That is a block Cholesky of the
+// permuted matrix (backward stable for an SPD matrix), log2(N) levels deep, and every level is
+// made of dense MP x MP operations (MP = M rounded up to 16) that fill the chip:
+//
+//   bcr_potrf_kernel   L_j = chol(D_j) and its inverse, in LDS, 16x16 tiles on the f64 MFMA
+//                      (left-looking; the diagonal tile in wave-0 registers with readlane broadcasts)
+//   bcr_x_kernel       XA_j = L_j^-1 C_a,  XB_j = L_j^-1 C_j^T            (a = j-s, b = j+s)
+//   bcr_upd_kernel     D_a -= XA_j^T XA_j (+ XB_j'^T XB_j' from the other side),  C_a = -XB_j^T XA_j
+//
+// (64x64 output tiles, v_mfma_f64_16x16x4_f64, operands staged through LDS in 32-deep chunks).
+// The substitutions walk the same levels with matrix-vector products:
+//   forward  z_j = L_j^-1 r_j ;  r_a -= XA_j^T z_j ;  r_b -= XB_j^T z_j
+//   backward p_j = L_j^-T (z_j - XA_j p_a - XB_j p_b)
+// Both orientations of L^-1, XA, XB are stored so that every product reads coalesced columns.
+// Explicit inverses of the (triangular) diagonal factors are accurate enough here because the
+// solve is refined iteratively against the matrix-free operator (tools/bcr_proto.py: the
+// gradient agrees with the banded solve to 4e-9).
+//
+// Block storage: column major, leading dimension MP; element (r, c) at r + MP*c; block j of image
+// k at ((k*N + j) * MP*MP).  Padding rows/columns (r >= M) carry the identity.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "adjoint_kernels.hpp"
+
+namespace bpltv {
+
+typedef double bcr_d4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int bcr_levels(int N) {
+    int L = 0;
+    while ((1 << L) < N) ++L;
+    return L;
+}
+// blocks eliminated at level l: j = s + 2s*t < N
+__host__ __device__ inline int bcr_nelim(int N, int l) {
+    const int s = 1 << l;
+    return N > s ? (N - s + 2 * s - 1) / (2 * s) : 0;
+}
+// blocks that survive level l: a = 2s*t < N
+__host__ __device__ inline int bcr_nsurv(int N, int l) {
+    const int s = 1 << l;
+    return (N + 2 * s - 1) / (2 * s);
+}
+
+__device__ __forceinline__ bcr_d4 bcr_mfma(double a, double b, bcr_d4 c) {
+    // v_mfma_f64_16x16x4_f64: lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15];
+    // result register g of lane l is C[row = (l>>4) + 4g][col = l&15].
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Dense blocks from the four assembled diagonals.  grid (N, O), block 256.
+__global__ __launch_bounds__(256) void bcr_init_kernel(const double* __restrict__ band4, int M, int N, int O,
+                                                       int MP, double* __restrict__ D, double* __restrict__ C) {
+    const int j = blockIdx.x, img = blockIdx.y;
+    const size_t npx = (size_t)M * N, tot = npx * O;
+    const size_t q0 = (size_t)img * npx + (size_t)j * M;
+    const size_t bo = ((size_t)img * N + j) * MP * MP;
+    for (int e = threadIdx.x; e < MP * MP; e += 256) {
+        const int r = e % MP, c = e / MP;
+        double d = 0.0, cc = 0.0;
+        if (r < M && c < M) {
+            if (r == c) d = band4[q0 + r];
+            else if (r == c + 1) d = band4[tot + q0 + c];
+            else if (c == r + 1) d = band4[tot + q0 + r];
+            if (j + 1 < N) {
+                if (r == c) cc = band4[3 * tot + q0 + c];            // A[q+M, q]
+                else if (r == c - 1) cc = band4[2 * tot + q0 + c];   // A[q+M-1, q]
+            }
+        } else if (r == c) {
+            d = 1.0;
+        }
+        D[bo + e] = d;
+        C[bo + e] = cc;
+    }
+}
+
+// Cholesky factor of the 16x16 tile T (LDS, leading dimension ld) and its inverse, by one wave:
+// lane r holds row r, pivots and multipliers travel by readlane.  On exit the tile holds W = L^-1
+// (lower triangular, explicit zeros above).  Returns true on a non-positive pivot.
+__device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, int lane) {
+    const int lr = lane & 15;
+    double m[16], di[16], x[16];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m[c] = T[lr + ld * c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double piv = readlane_f64(m[c], c);
+        if (!(piv > 0.0)) bad = true;
+        double d;
+        sqrt_rsqrt(piv, d, di[c]);
+        m[c] = (lr == c) ? d : m[c] * di[c];
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) {
+            const double lq = readlane_f64(m[c], q);
+            m[q] = __builtin_fma(-m[c], lq, m[q]);
+        }
+    }
+    // lane c computes column c of W = L^-1 by forward substitution; L(r, k) is read back from the
+    // tile as an LDS broadcast (120 readlane pairs would not fit the SGPR file)
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[lane + ld * c] = m[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double acc = (lr == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc = __builtin_fma(-T[r + ld * k], x[k], acc);
+        x[r] = acc * di[r];
+        asm volatile("" : "+v"(x[r]) : : "memory");  // row by row: keeps the 120 LDS loads from being hoisted into 240 live registers
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[r + ld * lane] = x[r];
+    }
+    return bad;
+}
+
+// Cholesky factor of D_j and its inverse, in LDS.  grid (nelim, O) (or (1, O) with s = 0 for the
+// last block 0), block BCR_PT; dynamic LDS (MP+1)*MP doubles.  On exit D_j holds L^-1 (lower
+// triangular, zeros above) and DT_j its transpose.
+constexpr int BCR_PT = 512;
+__global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ D, double* __restrict__ DT, int N,
+                                                           int MP, int s, int* __restrict__ fail) {
+    extern __shared__ double S[];
+    const int ld = MP + 1, P = MP >> 4;
+    const int img = blockIdx.y;
+    const int j = (s == 0) ? 0 : s + 2 * s * (int)blockIdx.x;
+    const size_t bo = ((size_t)img * N + j) * MP * MP;
+    double* Dj = D + bo;
+    double* DTj = DT + bo;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        S[r + ld * c] = Dj[e];
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int p = 0; p < P; ++p) {
+        // (1) left-looking update of block column p: tile (i, p) -= sum_{q<p} L_iq L_pq^T
+        if (p > 0) {
+            for (int i = p + wave; i < P; i += BCR_PT / 64) {
+                bcr_d4 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)];
+                for (int q = 0; q < p; ++q) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
+                        const double b = S[(16 * p + lr) + ld * (16 * q + 4 * kk + lk)];
+                        acc = bcr_mfma(-a, b, acc);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)] = acc[g];
+            }
+            __syncthreads();
+        }
+        // (2) diagonal tile: Cholesky and inverse in wave-0 registers (lane r holds row r)
+        if (wave == 0) bad |= bcr_diag_tile(S + (16 * p) + ld * (16 * p), ld, lane);
+        __syncthreads();
+        // (3) rows below: L_ip = A_ip W_pp^T      (4) inverse row panel: W_pq = -W_pp sum_k L_pk W_kq
+        //     W_kq (k >= q) is kept in the upper tile (q, k): element (r', c') at S[(16q+r') + ld(16k+c')]
+        for (int task = wave; task < P - 1; task += BCR_PT / 64) {
+            if (task < P - p - 1) {
+                const int i = p + 1 + task;
+                bcr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = S[(16 * i + lr) + ld * (16 * p + 4 * kk + lk)];
+                    const double b = S[(16 * p + lr) + ld * (16 * p + 4 * kk + lk)];  // W_pp(col, k)
+                    acc = bcr_mfma(a, b, acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)] = acc[g];
+            } else {
+                const int q = task - (P - p - 1);
+                bcr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k = q; k < p; ++k) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = S[(16 * p + lr) + ld * (16 * k + 4 * kk + lk)];      // L_pk(r, k')
+                        const double b = S[(16 * q + 4 * kk + lk) + ld * (16 * k + lr)];      // W_kq(k', col)
+                        acc = bcr_mfma(a, b, acc);
+                    }
+                }
+                bcr_d4 out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = S[(16 * p + lr) + ld * (16 * p + 4 * kk + lk)];          // W_pp(r, k')
+                    out = bcr_mfma(-a, acc[kk], out);  // the accumulator tile is the B operand of k-step kk
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) S[(16 * q + lk + 4 * g) + ld * (16 * p + lr)] = out[g];
+            }
+        }
+        __syncthreads();
+    }
+    if (bad && lane == 0 && fail[img] == 0) fail[img] = j + 1;
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        double v = 0.0, w = 0.0;
+        if (r >= c) v = S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))];
+        if (c >= r) w = S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))];
+        Dj[e] = v;    // L^-1 (r, c)
+        DTj[e] = w;   // L^-T (r, c) = L^-1 (c, r)
+    }
+}
+
+// ---- 64x64 output tile of sum_prod A B on the f64 MFMA ------------------------------------------
+constexpr int BG_T = 256;   // 4 waves, each a 32x32 quarter of the tile
+constexpr int BG_KC = 32;   // depth of one staged chunk
+constexpr int BG_LD = 65;
+
+// 64 x BG_KC chunk of Op(rr, kk), rr in [r0, r0+64), kk in [k0, k0+BG_KC) -> v[8] (zero outside MP).
+// RFAST: element (rr, kk) at rr + MP*kk; otherwise at kk + MP*rr.
+template <bool RFAST>
+__device__ __forceinline__ void bg_fetch(const double* __restrict__ base, int MP, int r0, int k0, int tid,
+                                         double (&v)[8]) {
+    if (RFAST) {
+        const int r = r0 + (tid & 63), kq = k0 + (tid >> 6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = kq + 4 * i;
+            v[i] = (r < MP && k < MP) ? base[r + (size_t)MP * k] : 0.0;
+        }
+    } else {
+        const int k = k0 + (tid & 31), rq = r0 + (tid >> 5);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = rq + 8 * i;
+            v[i] = (r < MP && k < MP) ? base[k + (size_t)MP * r] : 0.0;
+        }
+    }
+}
+template <bool RFAST>
+__device__ __forceinline__ void bg_stage(double* __restrict__ Ls, int tid, const double (&v)[8]) {
+    if (RFAST) {
+        const int r = tid & 63, kq = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Ls[(kq + 4 * i) * BG_LD + r] = v[i];
+    } else {
+        const int k = tid & 31, rq = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Ls[k * BG_LD + rq + 8 * i] = v[i];
+    }
+}
+
+struct BgAcc { bcr_d4 c[2][2]; };
+
+// acc += A B over the full depth MP.  ARF: A(r,k) at r + MP k (else k + MP r); BCF: B(k,c) at c + MP k
+// (else k + MP c).  lds: 2 * BG_KC * BG_LD doubles.
+template <bool ARF, bool BCF>
+__device__ __forceinline__ void bg_product(const double* __restrict__ A, const double* __restrict__ B, int MP,
+                                           int r0, int c0, int kend, double* __restrict__ lds, BgAcc& acc) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    double* As = lds;
+    double* Bs = lds + BG_KC * BG_LD;
+    for (int k0 = 0; k0 < kend; k0 += BG_KC) {
+        double va[8], vb[8];
+        bg_fetch<ARF>(A, MP, r0, k0, tid, va);
+        bg_fetch<BCF>(B, MP, c0, k0, tid, vb);
+        __syncthreads();  // the previous chunk has been consumed
+        bg_stage<ARF>(As, tid, va);
+        bg_stage<BCF>(Bs, tid, vb);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BG_KC / 4; ++kk) {
+            const int ko = (4 * kk + lk) * BG_LD;
+            const double a0 = As[ko + wr + lr], a1 = As[ko + wr + 16 + lr];
+            const double b0 = Bs[ko + wc + lr], b1 = Bs[ko + wc + 16 + lr];
+            acc.c[0][0] = bcr_mfma(a0, b0, acc.c[0][0]);
+            acc.c[0][1] = bcr_mfma(a0, b1, acc.c[0][1]);
+            acc.c[1][0] = bcr_mfma(a1, b0, acc.c[1][0]);
+            acc.c[1][1] = bcr_mfma(a1, b1, acc.c[1][1]);
+        }
+    }
+}
+
+// accumulators -> LDS tile T[c*BG_LD + r] (64 x 64), after all waves are done with the staging buffers
+__device__ __forceinline__ void bg_to_lds(const BgAcc& acc, double* __restrict__ T) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                T[(wc + 16 * tj + lr) * BG_LD + wr + 16 * ti + lk + 4 * g] = acc.c[ti][tj][g];
+    __syncthreads();
+}
+
+constexpr int BG_LDS = 64 * BG_LD;  // doubles: staging (2*32*65) and the output tile (64*65) share it
+
+// XA_j = Linv_j C_a,  XB_j = Linv_j C_j^T, both orientations stored.
+// grid (nt*nt, 2*nelim, O), nt = ceil(MP/64); block BG_T.
+__global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ Linv, const double* __restrict__ C,
+                                                     double* __restrict__ XA, double* __restrict__ XAT,
+                                                     double* __restrict__ XB, double* __restrict__ XBT, int N,
+                                                     int MP, int s) {
+    __shared__ double lds[BG_LDS];
+    const int nt = (MP + 63) / 64;
+    const int r0 = ((int)blockIdx.x % nt) * 64, c0 = ((int)blockIdx.x / nt) * 64;
+    const int which = blockIdx.y & 1, t = blockIdx.y >> 1, img = blockIdx.z;
+    const int j = s + 2 * s * t, a = j - s, b = j + s;
+    if (which == 1 && b >= N) return;
+    const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
+    const double* Lj = Linv + (ib + j) * bsz;
+    BgAcc acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    int kend = r0 + 64;  // Linv is lower triangular: columns beyond the tile's last row are zero
+    if (kend > MP) kend = MP;
+    double *X, *XT;
+    if (which == 0) {
+        bg_product<true, false>(Lj, C + (ib + a) * bsz, MP, r0, c0, kend, lds, acc);
+        X = XA + (ib + j) * bsz; XT = XAT + (ib + j) * bsz;
+    } else {
+        bg_product<true, true>(Lj, C + (ib + j) * bsz, MP, r0, c0, kend, lds, acc);
+        X = XB + (ib + j) * bsz; XT = XBT + (ib + j) * bsz;
+    }
+    bg_to_lds(acc, lds);
+    const int tid = threadIdx.x;
+    const int l = tid & 63, h = tid >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int o = h + 4 * i;
+        if (r0 + l < MP && c0 + o < MP) X[(r0 + l) + (size_t)MP * (c0 + o)] = lds[o * BG_LD + l];    // (r=l, c=o)
+        if (c0 + l < MP && r0 + o < MP) XT[(c0 + l) + (size_t)MP * (r0 + o)] = lds[l * BG_LD + o];   // (c=l, r=o)
+    }
+}
+
+// Schur update of the surviving blocks a = 2s*t:
+//   which 0:  D_a -= XA_{a+s}^T XA_{a+s} + XB_{a-s}^T XB_{a-s}
+//   which 1:  C_a  = -XB_{a+s}^T XA_{a+s}                       (new coupling of a+2s with a)
+// grid (nt*nt, 2*nsurv, O); block BG_T.
+__global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, double* __restrict__ C,
+                                                       const double* __restrict__ XA, const double* __restrict__ XAT,
+                                                       const double* __restrict__ XB, const double* __restrict__ XBT,
+                                                       int N, int MP, int s) {
+    __shared__ double lds[BG_LDS];
+    const int nt = (MP + 63) / 64;
+    const int r0 = ((int)blockIdx.x % nt) * 64, c0 = ((int)blockIdx.x / nt) * 64;
+    const int which = blockIdx.y & 1, t = blockIdx.y >> 1, img = blockIdx.z;
+    const int a = 2 * s * t;
+    const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
+    if (which == 1 && a + 2 * s >= N) return;
+    if (which == 0 && a + s >= N && a < s) return;
+    BgAcc acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    double* Out;
+    if (which == 0) {
+        if (a + s < N) bg_product<true, false>(XAT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, MP, r0, c0, MP, lds, acc);
+        if (a >= s) bg_product<true, false>(XBT + (ib + a - s) * bsz, XB + (ib + a - s) * bsz, MP, r0, c0, MP, lds, acc);
+        Out = D + (ib + a) * bsz;
+    } else {
+        bg_product<true, false>(XBT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, MP, r0, c0, MP, lds, acc);
+        Out = C + (ib + a) * bsz;
+    }
+    bg_to_lds(acc, lds);
+    const int tid = threadIdx.x;
+    const int l = tid & 63, h = tid >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int o = h + 4 * i;
+        if (r0 + l < MP && c0 + o < MP) {
+            const size_t e = (r0 + l) + (size_t)MP * (c0 + o);
+            const double v = lds[o * BG_LD + l];
+            Out[e] = (which == 0) ? Out[e] - v : -v;
+        }
+    }
+}
+
+// ---- substitutions -------------------------------------------------------------------------------
+// Matrix-vector products with MP x MP blocks are pure memory latency: a block is 128 KB and a
+// workgroup that loops over it with a few loads in flight sees ~10 GB/s.  Here the whole block is
+// requested at once: 16 waves, lane l owns the rows (2l, 2l+1) (one 16-byte load per column), wave w
+// owns the MP/16 columns [w*MP/16, (w+1)*MP/16); the 16 partial sums per row meet in LDS.
+constexpr int BS_T = 1024;
+constexpr int BS_MP = 128;  // largest MP
+constexpr int BS_W = BS_T / 64;
+
+// mode 0 full, 1 lower triangular (Mx(r,k) = 0 for k > r), 2 upper triangular (Mx(r,k) = 0 for k < r)
+__device__ __forceinline__ void bcr_mv_partial(const double* __restrict__ Mx, int MP, const double* __restrict__ v,
+                                               int mode, double& s0, double& s1) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = 2 * lane, cw = MP >> 4, k0 = cw * w;
+    if (r >= MP) return;
+    double2 m[8];
+    bool on[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i;
+        on[i] = (i < cw) && !(mode == 1 && k > r + 1) && !(mode == 2 && k < r);
+        if (on[i]) m[i] = *reinterpret_cast<const double2*>(Mx + r + (size_t)MP * k);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (on[i]) {
+            const double vk = v[k0 + i];
+            s0 = __builtin_fma(m[i].x, vk, s0);
+            s1 = __builtin_fma(m[i].y, vk, s1);
+        }
+}
+
+// partial sums -> red[w][row]; returns the row sum for tid < MP (all threads must call)
+__device__ __forceinline__ double bcr_mv_reduce(double* __restrict__ red, int MP, double s0, double s1) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (2 * lane < MP) *reinterpret_cast<double2*>(red + w * BS_MP + 2 * lane) = double2{s0, s1};
+    __syncthreads();
+    double sum = 0.0;
+    if (tid < MP) {
+#pragma unroll
+        for (int q = 0; q < BS_W; ++q) sum += red[q * BS_MP + tid];
+    }
+    __syncthreads();
+    return sum;
+}
+
+// z_j = Linv_j r_j for the blocks eliminated at level 0 (j odd).  grid (nelim(0), O), block BS_T.
+__global__ __launch_bounds__(BS_T) void bcr_fz_kernel(const double* __restrict__ Linv, int M, int N, int MP,
+                                                      double* __restrict__ vec) {
+    __shared__ double v[BS_MP];
+    __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
+    const int j = 1 + 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    double* vj = vec + ((size_t)img * N + j) * M;
+    if (tid < MP) v[tid] = (tid < M) ? vj[tid] : 0.0;
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    bcr_mv_partial(Linv + ((size_t)img * N + j) * MP * MP, MP, v, 1, s0, s1);
+    const double z = bcr_mv_reduce(red, MP, s0, s1);
+    if (tid < M) vj[tid] = z;
+}
+
+// Forward step of level l for the surviving blocks a = 2s*t:
+//   r_a -= XA_{a+s}^T z_{a+s} + XB_{a-s}^T z_{a-s}       (level 0, band4 != null: operator form, see below);
+//   if a is eliminated at the next level (or is the last block): z_a = Linv_a r_a,
+//   and for the last block also p_0 = Linv_0^T z_0 (+= into accv).
+// grid (nsurv(l), O), block BS_T.
+__global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict__ Linv, const double* __restrict__ LinvT,
+                                                       const double* __restrict__ XAT, const double* __restrict__ XBT,
+                                                       int M, int N, int MP, int s, int last,
+                                                       double* __restrict__ vec, double* __restrict__ accv,
+                                                       const double* __restrict__ band4, int O) {
+    __shared__ double za[BS_MP], zb[BS_MP], rn[BS_MP];
+    __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
+    const int t = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int a = 2 * s * t;
+    const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
+    double* va = vec + (ib + a) * M;
+    const bool hasA = (a + s < N), hasB = (a >= s);
+    if (tid < MP) {
+        za[tid] = (hasA && tid < M) ? vec[(ib + a + s) * M + tid] : 0.0;
+        zb[tid] = (hasB && tid < M) ? vec[(ib + a - s) * M + tid] : 0.0;
+    }
+    const double rold = (tid < M) ? va[tid] : 0.0;
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    double rnew;
+    if (band4) {
+        // level 0 in operator form (za = y_{a+1}, zb = y_{a-1}):  r_a -= C_a^T y_{a+1} + C_{a-1} y_{a-1}
+        double t = 0.0;
+        if (tid < M) {
+            const size_t tot = (size_t)M * N * O, qa = (ib + a) * M;
+            if (hasA) t += band4[3 * tot + qa + tid] * za[tid] + ((tid >= 1) ? band4[2 * tot + qa + tid] * za[tid - 1] : 0.0);
+            if (hasB)
+                t += band4[3 * tot + qa - M + tid] * zb[tid] +
+                     ((tid + 1 < M) ? band4[2 * tot + qa - M + tid + 1] * zb[tid + 1] : 0.0);
+        }
+        rnew = rold - t;
+    } else {
+        if (hasA) bcr_mv_partial(XAT + (ib + a + s) * bsz, MP, za, 0, s0, s1);
+        if (hasB) bcr_mv_partial(XBT + (ib + a - s) * bsz, MP, zb, 0, s0, s1);
+        rnew = rold - bcr_mv_reduce(red, MP, s0, s1);
+    }
+    const bool top = last != 0;                        // only a = 0 survives the last level
+    const bool next = top || ((t & 1) != 0);           // eliminated at level l+1
+    if (!next) {
+        if (tid < M) va[tid] = rnew;
+        return;
+    }
+    if (tid < MP) rn[tid] = (tid < M) ? rnew : 0.0;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    bcr_mv_partial(Linv + (ib + a) * bsz, MP, rn, 1, s0, s1);
+    const double z = bcr_mv_reduce(red, MP, s0, s1);
+    if (!top) {
+        if (tid < M) va[tid] = z;
+        return;
+    }
+    if (tid < MP) za[tid] = (tid < M) ? z : 0.0;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    bcr_mv_partial(LinvT + (ib + a) * bsz, MP, za, 2, s0, s1);
+    const double p = bcr_mv_reduce(red, MP, s0, s1);
+    if (tid < M) {
+        va[tid] = p;
+        if (accv) accv[(ib + a) * M + tid] += p;
+    }
+}
+
+// Backward step of level l for the eliminated blocks j = s + 2s*t:
+//   p_j = Linv_j^T (z_j - XA_j p_a - XB_j p_b)   (+= into accv).   grid (nelim(l), O), block BS_T.
+__global__ __launch_bounds__(BS_T) void bcr_bwd_kernel(const double* __restrict__ LinvT, const double* __restrict__ XA,
+                                                       const double* __restrict__ XB, int M, int N, int MP, int s,
+                                                       double* __restrict__ vec, double* __restrict__ accv) {
+    __shared__ double pa[BS_MP], pb[BS_MP], w[BS_MP];
+    __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
+    const int t = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int j = s + 2 * s * t, a = j - s, b = j + s;
+    const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
+    const bool hasB = b < N;
+    double* vj = vec + (ib + j) * M;
+    if (tid < MP) {
+        pa[tid] = (tid < M) ? vec[(ib + a) * M + tid] : 0.0;
+        pb[tid] = (hasB && tid < M) ? vec[(ib + b) * M + tid] : 0.0;
+    }
+    const double zj = (tid < M) ? vj[tid] : 0.0;
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    bcr_mv_partial(XA + (ib + j) * bsz, MP, pa, 0, s0, s1);
+    if (hasB) bcr_mv_partial(XB + (ib + j) * bsz, MP, pb, 0, s0, s1);
+    const double acc = bcr_mv_reduce(red, MP, s0, s1);
+    if (tid < MP) w[tid] = (tid < M) ? zj - acc : 0.0;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    bcr_mv_partial(LinvT + (ib + j) * bsz, MP, w, 2, s0, s1);
+    const double p = bcr_mv_reduce(red, MP, s0, s1);
+    if (tid < M) {
+        vj[tid] = p;
+        if (accv) accv[(ib + j) * M + tid] += p;
+    }
+}
+
+// ---- level 0 in operator form -----------------------------------------------------------------------
+// The blocks eliminated first (j odd) are still sparse: D_j = T is tridiagonal and the couplings
+// C_a (a = j-1) and C_j are bidiagonal.  Treating them as dense blocks makes level 0 half of all the
+// work and memory traffic, so level 0 keeps them as what they are:
+//   * T = L D L^T (pivots ell_i, 1/delta_i per odd block, [O][N][M]) and tridiagonal solves (Thomas);
+//   * (C_a p)(r)   = g_a[r] p(r) + h_a[r+1] p(r+1)      (block a -> block a+1)
+//     (C_a^T y)(c) = g_a[c] y(c) + h_a[c] y(c-1)        (block a+1 -> block a)
+//     with g_a = the assembled diagonal at offset M, h_a = the one at offset M-1 (band4 planes 3, 2);
+//   * the Schur complements that level 1 starts from,
+//       D_a  <- T_a - XA^T XA - XB'^T XB',   C'_a = -XB^T XA,     X = D^-1/2 L^-1 C  (as in the dense levels),
+//     in closed form.  A column of L^-1 C is one "head" entry followed by a geometric tail:
+//       w = (0 .. 0, eta at s-1, omega at s, omega*v(s,s+1), omega*v(s,s+2), ...),  v(s,i) = prod_{m=s}^{i-1} (-ell_m)
+//     (XA column c: s = c, eta = h_a[c], omega = g_a[c] - ell_{c-1} eta;  XB column r: s = r+1, eta = g_j[r],
+//     omega = h_j[r+1] - ell_r eta), so for s <= s'
+//       <w, w'> = [s = s'] eta eta'/delta_{s-1} + [s < s'] eta' omega v(s,s'-1)/delta_{s'-1} + omega omega' v(s,s') Q_{s'}
+//     with Q_s = sum_{i>=s} v(s,i)^2/delta_i = 1/delta_s + ell_s^2 Q_{s+1}: products and sums of positive
+//     terms only, O(1) per entry with a running product.  (Forming T^-1 by Thomas solves and applying the
+//     4-term stencil of C^T T^-1 C instead loses the positive definiteness at kappa = 1e14: tried.)
+// No dense block is read or written for an odd block, and no product runs on them.
+
+// Thomas solve T x = v with the pivots (ell, invd) by ONE lane; all arrays in LDS, x may alias v.
+__device__ __forceinline__ void bcr0_thomas(const double* __restrict__ ell, const double* __restrict__ invd,
+                                            const double* v, double* x, int M) {
+    double w = v[0];
+    x[0] = w;
+    for (int i = 1; i < M; ++i) {
+        w = __builtin_fma(-ell[i - 1], w, v[i]);
+        x[i] = w;
+    }
+    double xn = x[M - 1] * invd[M - 1];
+    x[M - 1] = xn;
+    for (int i = M - 2; i >= 0; --i) {
+        xn = __builtin_fma(-ell[i], xn, x[i] * invd[i]);
+        x[i] = xn;
+    }
+}
+
+// pivots of the tridiagonal (d, e) by ONE lane (LDS arrays): delta_0 = d_0, ell_i = e_i/delta_i,
+// delta_{i+1} = d_{i+1} - ell_i e_i; then Q (M+1 entries).  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool bcr0_pivots(const double* __restrict__ d, const double* __restrict__ e,
+                                            double* __restrict__ ell, double* __restrict__ invd,
+                                            double* __restrict__ Q, int M) {
+    double del = d[0];
+    bool ok = del > 0.0;
+    for (int i = 0; i < M; ++i) {
+        const double inv = 1.0 / del;
+        invd[i] = inv;
+        if (i + 1 < M) {
+            const double l = e[i] * inv;
+            ell[i] = l;
+            del = __builtin_fma(-l, e[i], d[i + 1]);
+            ok = ok && (del > 0.0);
+        } else {
+            ell[i] = 0.0;
+        }
+    }
+    double q = 0.0;
+    Q[M] = 0.0;
+    for (int i = M - 1; i >= 0; --i) {
+        q = __builtin_fma(ell[i] * ell[i], q, invd[i]);
+        Q[i] = q;
+    }
+    return ok;
+}
+
+// Gram matrix of one family of columns (tail start s = x + off) into S (both triangles), threads x < M.
+__device__ __forceinline__ void bcr0_gram(double* __restrict__ S, int ld, int M, int off, const double* __restrict__ eta,
+                                          const double* __restrict__ om, const double* __restrict__ ell,
+                                          const double* __restrict__ invd, const double* __restrict__ Q, int x) {
+    const int s = x + off;
+    const double ex = eta[x], ox = om[x];
+    S[x + ld * x] = ((s >= 1) ? invd[s - 1] * ex * ex : 0.0) + ((s < M) ? ox * ox * Q[s] : 0.0);
+    double v = 1.0;  // v(s, s'-1)
+    for (int y = x + 1; y < M; ++y) {
+        const int sp = y + off;          // s' - 1 >= s, s' - 1 <= M - 1
+        const double head = invd[sp - 1] * eta[y] * (ox * v);
+        v *= -ell[sp - 1];               // v(s, s')
+        const double tail = (sp < M) ? (ox * om[y]) * v * Q[sp] : 0.0;
+        const double r = head + tail;
+        S[x + ld * y] = r;
+        S[y + ld * x] = r;
+    }
+}
+
+// Cross Gram matrix S(r, c) = <XB column r, XA column c> (XB: s = r+1; XA: s = c), threads r < M.
+__device__ __forceinline__ void bcr0_cross(double* __restrict__ S, int ld, int M, const double* __restrict__ etaB,
+                                           const double* __restrict__ omB, const double* __restrict__ etaA,
+                                           const double* __restrict__ omA, const double* __restrict__ ell,
+                                           const double* __restrict__ invd, const double* __restrict__ Q, int r) {
+    const int sb = r + 1;
+    const double eb = etaB[r], ob = omB[r];
+    // columns c >= r+1: the XB column starts first (s = sb <= s' = c)
+    if (sb < M) {
+        S[r + ld * sb] = invd[sb - 1] * eb * etaA[sb] + ob * omA[sb] * Q[sb];
+        double v = 1.0;  // v(sb, c-1)
+        for (int c = sb + 1; c < M; ++c) {
+            const double head = invd[c - 1] * etaA[c] * (ob * v);
+            v *= -ell[c - 1];
+            S[r + ld * c] = head + (ob * omA[c]) * v * Q[c];
+        }
+    }
+    // columns c <= r: the XA column starts first (s = c < s' = sb); head of the XB column at index r
+    double v = 1.0;      // v(c, r)
+    for (int c = r; c >= 0; --c) {
+        const double head = invd[r] * eb * (omA[c] * v);
+        const double tail = (sb < M) ? (omA[c] * ob) * (v * -ell[r]) * Q[sb] : 0.0;
+        S[r + ld * c] = head + tail;
+        if (c >= 1) v *= -ell[c - 1];
+    }
+}
+
+constexpr int B0_T = 1024;
+
+// Level-0 Schur complements.  grid (nsurv(0), O), block B0_T, dynamic LDS bcr0_schur_lds(MP).
+// Writes the dense D_a (Li slot) and C'_a (C slot) of every even block a and the pivots of block a+1.
+__global__ __launch_bounds__(B0_T) void bcr0_schur_kernel(const double* __restrict__ band4, int M, int N, int O, int MP,
+                                                          double* __restrict__ D, double* __restrict__ C,
+                                                          double* __restrict__ ell, double* __restrict__ invd,
+                                                          int* __restrict__ fail) {
+    extern __shared__ double S[];
+    const int ld = MP + 1;
+    double* co = S + (size_t)ld * MP;
+    const int MQ = MP + 1;
+    // per side (0 = block a-1, 1 = block a+1): d, e, ell, invd, Q
+    double *dd[2] = {co, co + MQ}, *ee[2] = {co + 2 * MQ, co + 3 * MQ};
+    double *ll[2] = {co + 4 * MQ, co + 5 * MQ}, *iv[2] = {co + 6 * MQ, co + 7 * MQ}, *QQ[2] = {co + 8 * MQ, co + 9 * MQ};
+    // couplings: g/h of C_{a-1}, C_a, C_{a+1};  omegas of the three column families
+    double *gl = co + 10 * MQ, *hl = co + 11 * MQ, *gu = co + 12 * MQ, *hu = co + 13 * MQ, *g2 = co + 14 * MQ,
+           *h2 = co + 15 * MQ, *oBl = co + 16 * MQ, *oA = co + 17 * MQ, *oB2 = co + 18 * MQ;
+    const int a = 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const size_t npx = (size_t)M * N, tot = npx * O;
+    const size_t qa = (size_t)img * npx + (size_t)a * M;   // first pixel of block a
+    const bool has[2] = {a >= 1, a + 1 < N};
+    const bool hasC2 = a + 2 < N;
+    if (tid < MP) {
+        const int i = tid;
+        const bool in = i < M;
+        dd[0][i] = (has[0] && in) ? band4[qa - M + i] : 1.0;
+        ee[0][i] = (has[0] && i + 1 < M) ? band4[tot + qa - M + i] : 0.0;
+        dd[1][i] = (has[1] && in) ? band4[qa + M + i] : 1.0;
+        ee[1][i] = (has[1] && i + 1 < M) ? band4[tot + qa + M + i] : 0.0;
+        gl[i] = (has[0] && in) ? band4[3 * tot + qa - M + i] : 0.0;             // C_{a-1}(r, r)
+        hl[i] = (has[0] && in && i >= 1) ? band4[2 * tot + qa - M + i] : 0.0;   // C_{a-1}(c-1, c)
+        gu[i] = (has[1] && in) ? band4[3 * tot + qa + i] : 0.0;                 // C_a
+        hu[i] = (has[1] && in && i >= 1) ? band4[2 * tot + qa + i] : 0.0;
+        g2[i] = (hasC2 && in) ? band4[3 * tot + qa + M + i] : 0.0;              // C_{a+1}
+        h2[i] = (hasC2 && in && i >= 1) ? band4[2 * tot + qa + M + i] : 0.0;
+    }
+    __syncthreads();
+    if ((tid == 0 && has[0]) || (tid == 64 && has[1])) {   // two waves, one lane each
+        const int sd = tid >> 6;
+        if (!bcr0_pivots(dd[sd], ee[sd], ll[sd], iv[sd], QQ[sd], M) && fail[img] == 0) fail[img] = a + (sd ? 2 : 0);
+    }
+    __syncthreads();
+    if (tid < M) {
+        const int i = tid;
+        if (has[1]) {   // the pivots of block a+1 serve the substitutions
+            const size_t o = ((size_t)img * N + a + 1) * M + i;
+            ell[o] = ll[1][i];
+            invd[o] = iv[1][i];
+        }
+        oBl[i] = (i + 1 < M) ? hl[i + 1] - ll[0][i] * gl[i] : 0.0;
+        oA[i] = gu[i] - ((i >= 1) ? ll[1][i - 1] * hu[i] : 0.0);
+        oB2[i] = (i + 1 < M) ? h2[i + 1] - ll[1][i] * g2[i] : 0.0;
+    }
+    __syncthreads();
+    const size_t bo = ((size_t)img * N + a) * MP * MP;
+    auto tridiag = [&](int r, int c) -> double {
+        if (r < M && c < M) {
+            if (r == c) return band4[qa + r];
+            if (r == c + 1) return band4[tot + qa + c];
+            if (c == r + 1) return band4[tot + qa + r];
+            return 0.0;
+        }
+        return (r == c) ? 1.0 : 0.0;
+    };
+    // the contributions travel through global memory (each thread re-reads its own entries)
+    if (has[0]) {   // XB'^T XB' of block a-1
+        if (tid < M) bcr0_gram(S, ld, M, 1, gl, oBl, ll[0], iv[0], QQ[0], tid);
+        __syncthreads();
+        for (int e = tid; e < MP * MP; e += B0_T) {
+            const int r = e % MP, c = e / MP;
+            D[bo + e] = tridiag(r, c) - ((r < M && c < M) ? S[r + ld * c] : 0.0);
+        }
+        __syncthreads();
+    } else {
+        for (int e = tid; e < MP * MP; e += B0_T) D[bo + e] = tridiag(e % MP, e / MP);
+    }
+    if (has[1]) {   // XA^T XA of block a+1, then the new coupling -XB^T XA
+        if (tid < M) bcr0_gram(S, ld, M, 0, hu, oA, ll[1], iv[1], QQ[1], tid);
+        __syncthreads();
+        for (int e = tid; e < MP * MP; e += B0_T) {
+            const int r = e % MP, c = e / MP;
+            if (r < M && c < M) D[bo + e] -= S[r + ld * c];
+        }
+        __syncthreads();
+        if (hasC2) {
+            if (tid < M) bcr0_cross(S, ld, M, g2, oB2, hu, oA, ll[1], iv[1], QQ[1], tid);
+            __syncthreads();
+            for (int e = tid; e < MP * MP; e += B0_T) {
+                const int r = e % MP, c = e / MP;
+                C[bo + e] = (r < M && c < M) ? -S[r + ld * c] : 0.0;
+            }
+        }
+    }
+}
+
+// y_j = T_j^-1 r_j for the odd blocks.  grid (nelim(0), O), block 64.
+__global__ __launch_bounds__(64) void bcr0_y_kernel(const double* __restrict__ ell, const double* __restrict__ invd,
+                                                    int M, int N, double* __restrict__ vec) {
+    __shared__ double l[BS_MP], iv[BS_MP], v[BS_MP];
+    const int j = 1 + 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const size_t o = ((size_t)img * N + j) * M;
+    for (int i = tid; i < M; i += 64) { l[i] = ell[o + i]; iv[i] = invd[o + i]; v[i] = vec[o + i]; }
+    __syncthreads();
+    if (tid == 0) bcr0_thomas(l, iv, v, v, M);
+    __syncthreads();
+    for (int i = tid; i < M; i += 64) vec[o + i] = v[i];
+}
+
+// p_j = y_j - T_j^-1 (C_a p_a + C_j^T p_b) for the odd blocks (+= into accv).  grid (nelim(0), O), block 64.
+__global__ __launch_bounds__(64) void bcr0_bwd_kernel(const double* __restrict__ band4,
+                                                      const double* __restrict__ ell, const double* __restrict__ invd,
+                                                      int M, int N, int O, double* __restrict__ vec,
+                                                      double* __restrict__ accv) {
+    __shared__ double l[BS_MP], iv[BS_MP], v[BS_MP], pa[BS_MP + 1], pb[BS_MP + 1];
+    const int j = 1 + 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const size_t npx = (size_t)M * N, tot = npx * O;
+    const size_t o = ((size_t)img * N + j) * M;           // == first pixel of block j
+    const bool hasB = j + 1 < N;
+    for (int i = tid; i < M; i += 64) {
+        l[i] = ell[o + i]; iv[i] = invd[o + i];
+        pa[i] = vec[o - M + i];
+        pb[i + 1] = hasB ? vec[o + M + i] : 0.0;           // pb[c] = p_b(c-1)
+    }
+    if (tid == 0) { pa[M] = 0.0; pb[0] = 0.0; }
+    __syncthreads();
+    for (int i = tid; i < M; i += 64) {
+        // (C_a p_a)(i) = g_a[i] p_a(i) + h_a[i+1] p_a(i+1);  (C_j^T p_b)(i) = g_j[i] p_b(i) + h_j[i] p_b(i-1)
+        const double ga = band4[3 * tot + o - M + i], ha = (i + 1 < M) ? band4[2 * tot + o - M + i + 1] : 0.0;
+        double t = ga * pa[i] + ha * pa[i + 1];
+        if (hasB) {
+            const double gj = band4[3 * tot + o + i], hj = (i >= 1) ? band4[2 * tot + o + i] : 0.0;
+            t += gj * pb[i + 1] + hj * pb[i];
+        }
+        v[i] = t;
+    }
+    __syncthreads();
+    if (tid == 0) bcr0_thomas(l, iv, v, v, M);
+    __syncthreads();
+    for (int i = tid; i < M; i += 64) {
+        const double p = vec[o + i] - v[i];
+        vec[o + i] = p;
+        if (accv) accv[o + i] += p;
+    }
+}
+
+// ---- host-side launch sequences -------------------------------------------------------------------
+struct BcrArrays {
+    double *Li, *LiT, *C, *XA, *XAT, *XB, *XBT;  // [O][N][MP*MP] each
+    double *ell, *invd;                            // pivots of the odd blocks, [O][N][M] each
+    static size_t doubles(int M, int N, int O, int MP) { return 7 * (size_t)O * N * MP * MP + 2 * (size_t)O * N * M; }
+    static BcrArrays carve(double* base, int M, int N, int O, int MP) {
+        const size_t a = (size_t)O * N * MP * MP;
+        return BcrArrays{base, base + a, base + 2 * a, base + 3 * a, base + 4 * a, base + 5 * a, base + 6 * a,
+                         base + 7 * a, base + 7 * a + (size_t)O * N * M};
+    }
+};
+inline size_t bcr_potrf_lds(int MP) { return (size_t)(MP + 1) * MP * sizeof(double); }
+inline size_t bcr0_schur_lds(int MP) { return ((size_t)(MP + 1) * MP + 19 * (size_t)(MP + 1)) * sizeof(double); }
+
+// Dense levels l >= l0 of the factorisation of the block tridiagonal matrices held in
+// (B.Li = diagonal blocks, B.C = couplings at stride 2^l0), then the last block.
+inline void bcr_factor_launch(hipStream_t st, const BcrArrays& B, int N, int O, int MP, int* d_fail, int l0 = 0) {
+    const int BL = bcr_levels(N);
+    const unsigned nt = (unsigned)((MP + 63) / 64);
+    for (int l = l0; l < BL; ++l) {
+        const int s = 1 << l, ne = bcr_nelim(N, l), ns = bcr_nsurv(N, l);
+        hipLaunchKernelGGL(bcr_potrf_kernel, dim3(ne, O), dim3(BCR_PT), bcr_potrf_lds(MP), st, B.Li, B.LiT, N, MP, s, d_fail);
+        hipLaunchKernelGGL(bcr_x_kernel, dim3(nt * nt, 2 * ne, O), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N,
+                           MP, s);
+        hipLaunchKernelGGL(bcr_upd_kernel, dim3(nt * nt, 2 * ns, O), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT,
+                           N, MP, s);
+    }
+    hipLaunchKernelGGL(bcr_potrf_kernel, dim3(1, O), dim3(BCR_PT), bcr_potrf_lds(MP), st, B.Li, B.LiT, N, MP, 0, d_fail);
+}
+
+// Assembled diagonals -> factorisation: level 0 in operator form, the rest dense.
+inline void bcr_factor_band4_launch(hipStream_t st, const BcrArrays& B, const double* band4, int M, int N, int O, int MP,
+                                    int* d_fail) {
+    hipLaunchKernelGGL(bcr0_schur_kernel, dim3(bcr_nsurv(N, 0), O), dim3(B0_T), bcr0_schur_lds(MP), st, band4, M, N, O, MP,
+                       B.Li, B.C, B.ell, B.invd, d_fail);
+    bcr_factor_launch(st, B, N, O, MP, d_fail, 1);
+}
+
+// vec <- A^-1 vec (in place, [O][N*M]); accv += the solution when non-null.  band4 != null: the
+// factorisation came from bcr_factor_band4_launch (level 0 in operator form).
+inline void bcr_solve_launch(hipStream_t st, const BcrArrays& B, int M, int N, int O, int MP, double* vec, double* accv,
+                             const double* band4 = nullptr) {
+    const int BL = bcr_levels(N);
+    if (band4)
+        hipLaunchKernelGGL(bcr0_y_kernel, dim3(bcr_nelim(N, 0), O), dim3(64), 0, st, B.ell, B.invd, M, N, vec);
+    else
+        hipLaunchKernelGGL(bcr_fz_kernel, dim3(bcr_nelim(N, 0), O), dim3(BS_T), 0, st, B.Li, M, N, MP, vec);
+    for (int l = 0; l < BL; ++l)
+        hipLaunchKernelGGL(bcr_fwd_kernel, dim3(bcr_nsurv(N, l), O), dim3(BS_T), 0, st, B.Li, B.LiT, B.XAT, B.XBT, M, N, MP,
+                           1 << l, (l == BL - 1) ? 1 : 0, vec, accv, (l == 0) ? band4 : (const double*)nullptr, O);
+    for (int l = BL - 1; l >= 1; --l)
+        hipLaunchKernelGGL(bcr_bwd_kernel, dim3(bcr_nelim(N, l), O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1 << l,
+                           vec, accv);
+    if (band4)
+        hipLaunchKernelGGL(bcr0_bwd_kernel, dim3(bcr_nelim(N, 0), O), dim3(64), 0, st, band4, B.ell, B.invd, M, N, O, vec,
+                           accv);
+    else
+        hipLaunchKernelGGL(bcr_bwd_kernel, dim3(bcr_nelim(N, 0), O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1, vec,
+                           accv);
+}
+
+}  // namespace bpltv

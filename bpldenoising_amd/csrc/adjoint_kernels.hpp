@@ -246,7 +246,7 @@ __global__ __launch_bounds__(ADJ_FT) void adj_factor_kernel(const double* __rest
             for (int b = 0; b < NB; ++b) {
                 int sb = slot0 + b; if (sb >= RS) sb -= RS;
 #pragma unroll
-                for (int a = b; a < NB; ++a) m[a][b] = win[sb * W + (a - b)];
+                for (int a = b; a < NB; ++a) m[a][b] = (a - b <= bw) ? win[sb * W + (a - b)] : 0.0;  // bw < NB-1: outside the band
             }
 #pragma unroll
             for (int c = 0; c < NB; ++c) {

@@ -16,6 +16,7 @@
 
 #include "../../include/bpltv.h"
 #include "adjoint_hbm_kernels.hpp"
+#include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
 
@@ -113,7 +114,11 @@ struct bpltv_handle {
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
     // adjoint workspace (lazy)
-    bool adj_ready = false;
+    bool adj_ready = false;   // common workspace
+    bool band_ready = false;  // banded Cholesky workspace (LDS window or HBM band)
+    bool bcr_ready = false;   // block cyclic reduction workspace
+    double* d_bcr = nullptr;  // 7 block arrays [O][N][MP*MP]: Linv, LinvT, C, XA, XAT, XB, XBT
+    int bcr_MP = 0;
     double* d_coef = nullptr;   // 8 planes
     double* d_band4 = nullptr;  // 4 planes
     double* d_L = nullptr;
@@ -525,10 +530,46 @@ size_t adj_factor_lds(int M, int NB) {  // ring (bw+NB) x (bw+1) + panel NB x (b
 int adj_alloc(bpltv_t* h) {
     if (h->adj_ready) return BPLTV_OK;
     const size_t tot = h->tot;
-    const size_t W = (size_t)h->M + 1;
-    h->adj_hbm = adj_factor_lds(h->M, 4) > 160 * 1024;
     HIPCHK(h, hipMalloc((void**)&h->d_coef, 8 * tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_band4, 4 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_resn, 2 * (size_t)h->O * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
+    h->adj_ready = true;
+    return BPLTV_OK;
+}
+
+// Block cyclic reduction (adjoint_bcr_kernels.hpp) applies to M <= 128, N >= 2; its seven block arrays
+// take 7*N*MP^2 doubles per image (117 MB for 128^2; the odd blocks' slots stay unused because level 0
+// runs in operator form).
+bool bcr_applicable(const bpltv_t* h) { return h->M <= BS_MP && h->N >= 2; }
+
+int bcr_alloc(bpltv_t* h) {
+    if (h->bcr_ready) return BPLTV_OK;
+    const int MP = (h->M + 15) / 16 * 16;
+    const size_t need = BcrArrays::doubles(h->M, h->N, h->O, MP) * sizeof(double);
+    size_t freeb = 0, totalb = 0;
+    (void)hipMemGetInfo(&freeb, &totalb);
+    if (need + (1ull << 30) > freeb)
+        return set_err(h, BPLTV_E_NOMEM, "adjoint gradient (block cyclic reduction): %.1f GB of HBM needed, %.1f GB free",
+                       need / 1e9, freeb / 1e9);
+    HIPCHK(h, hipMalloc((void**)&h->d_bcr, need));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_potrf_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(BS_MP)));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr0_schur_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr0_schur_lds(BS_MP)));
+    h->bcr_MP = MP;
+    h->bcr_ready = true;
+    return BPLTV_OK;
+}
+
+int band_alloc(bpltv_t* h) {
+    if (h->band_ready) return BPLTV_OK;
+    const size_t tot = h->tot;
+    const size_t W = (size_t)h->M + 1;
+    h->adj_hbm = adj_factor_lds(h->M, 4) > 160 * 1024;
     if (h->adj_hbm) {
         size_t freeb = 0, totalb = 0;
         (void)hipMemGetInfo(&freeb, &totalb);
@@ -567,19 +608,15 @@ int adj_alloc(bpltv_t* h) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
     }
-    HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_resn, 2 * (size_t)h->O * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
-    if (!h->adj_hbm)
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<4, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    h->adj_ready = true;
+    if (!h->adj_hbm) {
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 128>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<8, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_factor_kernel<4, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    h->band_ready = true;
     return BPLTV_OK;
 }
 
@@ -588,6 +625,21 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                       double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
+    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction
+    const int method = p.reserved[4];
+    if (method == 2 && !bcr_applicable(h))
+        return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
+                       h->M, h->N);
+    bool use_bcr = bcr_applicable(h) && method != 1;
+    if (use_bcr) {
+        rc = bcr_alloc(h);
+        if (rc == BPLTV_E_NOMEM && method == 0) use_bcr = false;  // the band needs 7x less memory
+        else if (rc) return rc;
+    }
+    if (!use_bcr) {
+        rc = band_alloc(h);
+        if (rc) return rc;
+    }
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
     const size_t tot = h->tot;
     const int patch = !(am == 1 && an == 1);
@@ -606,7 +658,14 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                        O, patch, reg, kact, C);
     hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
-    if (h->adj_hbm) {
+    // ---- block cyclic reduction -------------------------------------------------------------
+    const int MP = h->bcr_MP;
+    const BcrArrays bcr = BcrArrays::carve(h->d_bcr, M, N, O, MP);
+    if (use_bcr) {
+        bcr_factor_band4_launch(h->stream, bcr, h->d_band4, M, N, O, MP, h->d_fail);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (!use_bcr && h->adj_hbm) {
         const size_t W = (size_t)M + 1;
         const size_t nel = h->npx * W;  // per image
         const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
@@ -621,9 +680,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         }
         HIPCHK(h, hipGetLastError());
     }
-    const int tw = h->adj_twisted ? 1 : 0;
+    const int tw = (!use_bcr && h->adj_twisted) ? 1 : 0;
     const dim3 fgrid(O, tw ? 2 : 1);
-    if (h->adj_hbm) {
+    if (use_bcr || h->adj_hbm) {
         // factor done above
     } else if (M == 128)  // the size of every shipped dataset: addressing folded at compile time
         hipLaunchKernelGGL((adj_factor_kernel<8, 128>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
@@ -639,7 +698,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     const size_t mid_lds = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
     double* invF1 = h->d_invF + (size_t)O * nblk_tot * SB * SB;
     double* invB1 = h->d_invB + (size_t)O * nblk_tot * SB * SB;
-    if (h->adj_hbm) {
+    if (use_bcr) {
+        // the inverses of the diagonal factors come out of bcr_potrf_kernel
+    } else if (h->adj_hbm) {
         hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_band, M, N, (int)h->npx,
                            h->d_invF, h->d_invB);
     } else if (tw) {
@@ -654,7 +715,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                            h->d_invF, h->d_invB);
     }
     auto solve = [&](double* vec, double* accv) {
-        if (h->adj_hbm) {
+        if (use_bcr) {
+            bcr_solve_launch(h->stream, bcr, M, N, O, MP, vec, accv, h->d_band4);
+        } else if (h->adj_hbm) {
             // one launch per 64-column block; d_gpix is free during the solves and holds y
             const int n = (int)h->npx;
             const unsigned chunks = 1 + (unsigned)((M + SB - 1) / SB);
@@ -860,7 +923,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_bcr, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)

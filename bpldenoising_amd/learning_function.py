@@ -92,6 +92,7 @@ class TVSolver:
         chains = kw.pop("chains", None)
         dbg = kw.pop("dbg", None)
         serialize = kw.pop("serialize_chains", None)
+        adjm = kw.pop("adjoint_method", None)
         for k, v in kw.items():
             if k in _IGNORED:
                 continue
@@ -108,6 +109,8 @@ class TVSolver:
             p.reserved[2] = int(bool(serialize))  # replay launch chains one after the other (timing aid)
         if dbg is not None:
             p.reserved[3] = int(dbg)       # timing experiments only (wrong results), see PdhgArgs::dbg
+        if adjm is not None:
+            p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2}.get(adjm, adjm)  # adjoint factorisation
         return p
 
     def _batch(self, a, what):

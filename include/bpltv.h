@@ -70,7 +70,8 @@ typedef struct bpltv_params {
                             [1] number of independent launch chains (image groups replayed concurrently)
                             [2] 1 = replay those chains one after the other (isolated kernel timing)
                             [3] timing-experiment bit mask (results are wrong when set; see PdhgArgs::dbg)
-                            [4] unused                                                          */
+                            [4] adjoint factorisation: 0 automatic, 1 banded Cholesky, 2 block cyclic reduction
+                                (M <= 128, N >= 2; BPLTV_E_UNSUPPORTED otherwise)                   */
 } bpltv_params;
 
 typedef struct bpltv_stats {

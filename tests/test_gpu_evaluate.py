@@ -339,3 +339,53 @@ def test_adjoint_split_edge_cases(gpu_solver_cls, oracle, N):
         _, _, greg = s.evaluate(alpha, 0.0, maxiter=400)
         assert np.allclose(greg, oracle.gradient(alpha, u0, ub, reg=True), rtol=1e-7, atol=1e-11)
     s.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 5), (2, 3, 16), (1, 29, 37), (2, 64, 100), (1, 13, 128), (3, 40, 1)])
+def test_both_adjoint_factorisations_agree(gpu_solver_cls, oracle, shape):
+    """The adjoint system is solved by block cyclic reduction (default for M <= 128, N >= 2: level 0 in
+    operator form, dense MFMA levels above) or by the banded Cholesky; both must reproduce the oracle."""
+    O, N, M = shape
+    ub, f = synth_batch(O, N, M, seed=70 + N + M)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    for alpha in (0.1, np.array([[0.06], [0.15]]) if N >= 2 else np.array([[0.06, 0.15]])):
+        u0 = oracle.pdhg(f, alpha, maxiter=400)
+        g0 = oracle.gradient(alpha, u0, ub)
+        r0 = oracle.gradient(alpha, u0, ub, reg=True)
+        res = {}
+        for meth in ("band", "bcr"):
+            _, _, g = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method=meth)
+            _, _, r = s.evaluate(alpha, 0.0, maxiter=400, adjoint_method=meth)
+            assert np.allclose(g, g0, rtol=2e-6, atol=1e-9), (meth, shape)
+            assert np.allclose(r, r0, rtol=1e-7, atol=1e-11), (meth, shape)
+            res[meth] = (np.asarray(g), np.asarray(r))
+        assert np.allclose(res["band"][0], res["bcr"][0], rtol=1e-7, atol=1e-11)
+        # the same call twice is bitwise reproducible (no atomics anywhere in the factorisation)
+        _, _, g2 = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method="bcr")
+        assert np.array_equal(np.asarray(g2), res["bcr"][0])
+    s.close()
+
+
+def test_bcr_is_refused_where_it_does_not_apply(gpu_solver_cls):
+    from bpldenoising_amd._lib import BpltvError
+    ub, f = synth_batch(1, 3, 130, seed=5)       # M = 130 > 128
+    s = gpu_solver_cls(130, 3, 1)
+    s.set_data(ub, f)
+    with pytest.raises(BpltvError) as e:
+        s.evaluate(0.1, 0.1, maxiter=50, adjoint_method="bcr")
+    assert e.value.code == 6
+    u, c, g = s.evaluate(0.1, 0.1, maxiter=50)   # automatic choice: banded Cholesky
+    assert np.isfinite(g)
+    s.close()
+
+
+def test_bcr_kernel_unit_checks(gpu_solver_cls):
+    """tools/bcr_unit.hip: Cholesky+inverse tile kernel, the two MFMA product kernels and complete
+    factor/solve sequences (dense and operator-form level 0) against plain host loops."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "_bin", "bcr_unit")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
