@@ -224,16 +224,21 @@ constexpr int BG_T = 256;   // 4 waves, each a 32x32 quarter of the tile
 constexpr int BG_KC = 32;   // depth of one staged chunk
 constexpr int BG_LD = 65;
 
+// Staging layout of one 64 x BG_KC operand chunk: Ls[kk][r][q] = Op(r, 4kk + q) with a kk-stride of
+// BG_KS doubles -- the 64 lanes of an MFMA operand read (16 rows x 4 k) then fetch 64 consecutive
+// doubles (conflict free), and so do the staging writes of both operand orientations.
+constexpr int BG_KS = 64 * 4 + 4;
+
 // 64 x BG_KC chunk of Op(rr, kk), rr in [r0, r0+64), kk in [k0, k0+BG_KC) -> v[8] (zero outside MP).
 // RFAST: element (rr, kk) at rr + MP*kk; otherwise at kk + MP*rr.
 template <bool RFAST>
 __device__ __forceinline__ void bg_fetch(const double* __restrict__ base, int MP, int r0, int k0, int tid,
                                          double (&v)[8]) {
     if (RFAST) {
-        const int r = r0 + (tid & 63), kq = k0 + (tid >> 6);
+        const int r = r0 + (tid & 63), kq = k0 + 8 * (tid >> 6);   // 8 consecutive k of one row
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int k = kq + 4 * i;
+            const int k = kq + i;
             v[i] = (r < MP && k < MP) ? base[r + (size_t)MP * k] : 0.0;
         }
     } else {
@@ -248,40 +253,52 @@ __device__ __forceinline__ void bg_fetch(const double* __restrict__ base, int MP
 template <bool RFAST>
 __device__ __forceinline__ void bg_stage(double* __restrict__ Ls, int tid, const double (&v)[8]) {
     if (RFAST) {
-        const int r = tid & 63, kq = tid >> 6;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Ls[(kq + 4 * i) * BG_LD + r] = v[i];
+        const int r = tid & 63, kk = 2 * (tid >> 6);
+        double* d = Ls + kk * BG_KS + r * 4;
+        *reinterpret_cast<double4*>(d) = double4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<double4*>(d + BG_KS) = double4{v[4], v[5], v[6], v[7]};
     } else {
         const int k = tid & 31, rq = tid >> 5;
+        double* d = Ls + (k >> 2) * BG_KS + (k & 3);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Ls[k * BG_LD + rq + 8 * i] = v[i];
+        for (int i = 0; i < 8; ++i) d[(rq + 8 * i) * 4] = v[i];
     }
 }
 
 struct BgAcc { bcr_d4 c[2][2]; };
 
-// acc += A B over the full depth MP.  ARF: A(r,k) at r + MP k (else k + MP r); BCF: B(k,c) at c + MP k
-// (else k + MP c).  lds: 2 * BG_KC * BG_LD doubles.
+// acc += A0 B0 (+ A1 B1 when nprod = 2) over the depth [0, kend).  ARF: A(r,k) at r + MP k (else k + MP r);
+// BCF: B(k,c) at c + MP k (else k + MP c).  lds: 2 * BG_KC * BG_LD doubles.  The global loads of chunk
+// i+1 are issued before the MFMAs of chunk i and land in registers while those run.
 template <bool ARF, bool BCF>
-__device__ __forceinline__ void bg_product(const double* __restrict__ A, const double* __restrict__ B, int MP,
-                                           int r0, int c0, int kend, double* __restrict__ lds, BgAcc& acc) {
+__device__ __forceinline__ void bg_product(const double* __restrict__ A0, const double* __restrict__ B0,
+                                           const double* __restrict__ A1, const double* __restrict__ B1, int nprod,
+                                           int MP, int r0, int c0, int kend, double* __restrict__ lds, BgAcc& acc) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
     double* As = lds;
-    double* Bs = lds + BG_KC * BG_LD;
-    for (int k0 = 0; k0 < kend; k0 += BG_KC) {
-        double va[8], vb[8];
-        bg_fetch<ARF>(A, MP, r0, k0, tid, va);
-        bg_fetch<BCF>(B, MP, c0, k0, tid, vb);
+    double* Bs = lds + (BG_KC / 4) * BG_KS;
+    const int nk = (kend + BG_KC - 1) / BG_KC, nchunk = nk * nprod;
+    double va[8], vb[8];
+    bg_fetch<ARF>(A0, MP, r0, 0, tid, va);
+    bg_fetch<BCF>(B0, MP, c0, 0, tid, vb);
+    for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // the previous chunk has been consumed
         bg_stage<ARF>(As, tid, va);
         bg_stage<BCF>(Bs, tid, vb);
         __syncthreads();
+        if (ch + 1 < nchunk) {
+            const int nx = ch + 1;
+            const bool second = nx >= nk;
+            const int k0 = (second ? nx - nk : nx) * BG_KC;
+            bg_fetch<ARF>(second ? A1 : A0, MP, r0, k0, tid, va);
+            bg_fetch<BCF>(second ? B1 : B0, MP, c0, k0, tid, vb);
+        }
 #pragma unroll
         for (int kk = 0; kk < BG_KC / 4; ++kk) {
-            const int ko = (4 * kk + lk) * BG_LD;
-            const double a0 = As[ko + wr + lr], a1 = As[ko + wr + 16 + lr];
-            const double b0 = Bs[ko + wc + lr], b1 = Bs[ko + wc + 16 + lr];
+            const int ko = kk * BG_KS + lr * 4 + lk;
+            const double a0 = As[ko + wr * 4], a1 = As[ko + (wr + 16) * 4];
+            const double b0 = Bs[ko + wc * 4], b1 = Bs[ko + (wc + 16) * 4];
             acc.c[0][0] = bcr_mfma(a0, b0, acc.c[0][0]);
             acc.c[0][1] = bcr_mfma(a0, b1, acc.c[0][1]);
             acc.c[1][0] = bcr_mfma(a1, b0, acc.c[1][0]);
@@ -305,18 +322,38 @@ __device__ __forceinline__ void bg_to_lds(const BgAcc& acc, double* __restrict__
     __syncthreads();
 }
 
-constexpr int BG_LDS = 64 * BG_LD;  // doubles: staging (2*32*65) and the output tile (64*65) share it
+constexpr int BG_LDS = 2 * (BG_KC / 4) * BG_KS;  // doubles: staging (2 x 8 x 260) and the output tile (64 x 65) share it
+static_assert(BG_LDS >= 64 * BG_LD, "output tile must fit the staging buffers");
+
+// Workgroup id -> (product, tile).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with
+// its own L2; the nt*nt tiles of one product re-read the same operand panels, so they are given ids of
+// equal residue mod 8 (same XCD, dispatched together) and the second read of a panel hits that L2
+// instead of HBM.  Launch bg_grid(P, nt) workgroups; returns false for the padding ids.
+__host__ __device__ inline unsigned bg_grid(unsigned P, unsigned nt) { return ((P + 7) / 8) * 8 * nt * nt; }
+__device__ __forceinline__ bool bg_decode(unsigned id, unsigned P, int nt, unsigned& prod, int& r0, int& c0) {
+    const unsigned G = (unsigned)(nt * nt), span = 8 * G;
+    const unsigned q = id / span, rem = id - q * span;
+    const unsigned t = rem >> 3;
+    prod = 8 * q + (rem & 7);
+    r0 = (int)(t % nt) * 64;
+    c0 = (int)(t / nt) * 64;
+    return prod < P;
+}
 
 // XA_j = Linv_j C_a,  XB_j = Linv_j C_j^T, both orientations stored.
-// grid (nt*nt, 2*nelim, O), nt = ceil(MP/64); block BG_T.
+// grid bg_grid(2*nelim*O, nt), nt = ceil(MP/64); block BG_T.
 __global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ Linv, const double* __restrict__ C,
                                                      double* __restrict__ XA, double* __restrict__ XAT,
                                                      double* __restrict__ XB, double* __restrict__ XBT, int N,
-                                                     int MP, int s) {
-    __shared__ double lds[BG_LDS];
+                                                     int O, int MP, int s) {
+    __shared__ __attribute__((aligned(32))) double lds[BG_LDS];
     const int nt = (MP + 63) / 64;
-    const int r0 = ((int)blockIdx.x % nt) * 64, c0 = ((int)blockIdx.x / nt) * 64;
-    const int which = blockIdx.y & 1, t = blockIdx.y >> 1, img = blockIdx.z;
+    const unsigned ny = 2 * (unsigned)bcr_nelim(N, 31 - __builtin_clz(s));
+    unsigned prod;
+    int r0, c0;
+    if (!bg_decode(blockIdx.x, ny * (unsigned)O, nt, prod, r0, c0)) return;
+    const int yy = (int)(prod % ny), img = (int)(prod / ny);
+    const int which = yy & 1, t = yy >> 1;
     const int j = s + 2 * s * t, a = j - s, b = j + s;
     if (which == 1 && b >= N) return;
     const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
@@ -328,10 +365,10 @@ __global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ 
     if (kend > MP) kend = MP;
     double *X, *XT;
     if (which == 0) {
-        bg_product<true, false>(Lj, C + (ib + a) * bsz, MP, r0, c0, kend, lds, acc);
+        bg_product<true, false>(Lj, C + (ib + a) * bsz, nullptr, nullptr, 1, MP, r0, c0, kend, lds, acc);
         X = XA + (ib + j) * bsz; XT = XAT + (ib + j) * bsz;
     } else {
-        bg_product<true, true>(Lj, C + (ib + j) * bsz, MP, r0, c0, kend, lds, acc);
+        bg_product<true, true>(Lj, C + (ib + j) * bsz, nullptr, nullptr, 1, MP, r0, c0, kend, lds, acc);
         X = XB + (ib + j) * bsz; XT = XBT + (ib + j) * bsz;
     }
     bg_to_lds(acc, lds);
@@ -348,15 +385,19 @@ __global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ 
 // Schur update of the surviving blocks a = 2s*t:
 //   which 0:  D_a -= XA_{a+s}^T XA_{a+s} + XB_{a-s}^T XB_{a-s}
 //   which 1:  C_a  = -XB_{a+s}^T XA_{a+s}                       (new coupling of a+2s with a)
-// grid (nt*nt, 2*nsurv, O); block BG_T.
+// grid bg_grid(2*nsurv*O, nt); block BG_T.
 __global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, double* __restrict__ C,
                                                        const double* __restrict__ XA, const double* __restrict__ XAT,
                                                        const double* __restrict__ XB, const double* __restrict__ XBT,
-                                                       int N, int MP, int s) {
-    __shared__ double lds[BG_LDS];
+                                                       int N, int O, int MP, int s) {
+    __shared__ __attribute__((aligned(32))) double lds[BG_LDS];
     const int nt = (MP + 63) / 64;
-    const int r0 = ((int)blockIdx.x % nt) * 64, c0 = ((int)blockIdx.x / nt) * 64;
-    const int which = blockIdx.y & 1, t = blockIdx.y >> 1, img = blockIdx.z;
+    const unsigned ny = 2 * (unsigned)bcr_nsurv(N, 31 - __builtin_clz(s));
+    unsigned prod;
+    int r0, c0;
+    if (!bg_decode(blockIdx.x, ny * (unsigned)O, nt, prod, r0, c0)) return;
+    const int yy = (int)(prod % ny), img = (int)(prod / ny);
+    const int which = yy & 1, t = yy >> 1;
     const int a = 2 * s * t;
     const size_t bsz = (size_t)MP * MP, ib = (size_t)img * N;
     if (which == 1 && a + 2 * s >= N) return;
@@ -366,11 +407,16 @@ __global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, d
     for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
     double* Out;
     if (which == 0) {
-        if (a + s < N) bg_product<true, false>(XAT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, MP, r0, c0, MP, lds, acc);
-        if (a >= s) bg_product<true, false>(XBT + (ib + a - s) * bsz, XB + (ib + a - s) * bsz, MP, r0, c0, MP, lds, acc);
+        const bool up = a + s < N, lo = a >= s;
+        const double *P0t = XAT + (ib + a + s) * bsz, *P0 = XA + (ib + a + s) * bsz;
+        const double *P1t = XBT + (ib + a - s) * bsz, *P1 = XB + (ib + a - s) * bsz;
+        if (up && lo) bg_product<true, false>(P0t, P0, P1t, P1, 2, MP, r0, c0, MP, lds, acc);
+        else if (up) bg_product<true, false>(P0t, P0, nullptr, nullptr, 1, MP, r0, c0, MP, lds, acc);
+        else bg_product<true, false>(P1t, P1, nullptr, nullptr, 1, MP, r0, c0, MP, lds, acc);
         Out = D + (ib + a) * bsz;
     } else {
-        bg_product<true, false>(XBT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, MP, r0, c0, MP, lds, acc);
+        bg_product<true, false>(XBT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, nullptr, nullptr, 1, MP, r0, c0, MP, lds,
+                                acc);
         Out = C + (ib + a) * bsz;
     }
     bg_to_lds(acc, lds);
@@ -396,27 +442,38 @@ constexpr int BS_T = 1024;
 constexpr int BS_MP = 128;  // largest MP
 constexpr int BS_W = BS_T / 64;
 
+// A thread's slice of a block: rows (2l, 2l+1) x the wave's MP/16 <= 8 columns.  Loading and applying
+// are separate so that every block a kernel needs is requested up front -- also the blocks whose
+// right-hand side is only known after an earlier product (their latency is then hidden behind it).
+struct BcrSlice { double2 m[8]; };
+
 // mode 0 full, 1 lower triangular (Mx(r,k) = 0 for k > r), 2 upper triangular (Mx(r,k) = 0 for k < r)
-__device__ __forceinline__ void bcr_mv_partial(const double* __restrict__ Mx, int MP, const double* __restrict__ v,
-                                               int mode, double& s0, double& s1) {
+__device__ __forceinline__ void bcr_mv_load(const double* __restrict__ Mx, int MP, int mode, BcrSlice& t) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = 2 * lane, cw = MP >> 4, k0 = cw * w;
-    if (r >= MP) return;
-    double2 m[8];
-    bool on[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = k0 + i;
-        on[i] = (i < cw) && !(mode == 1 && k > r + 1) && !(mode == 2 && k < r);
-        if (on[i]) m[i] = *reinterpret_cast<const double2*>(Mx + r + (size_t)MP * k);
+        const bool on = (r < MP) && (i < cw) && !(mode == 1 && k > r + 1) && !(mode == 2 && k < r);
+        t.m[i] = on ? *reinterpret_cast<const double2*>(Mx + r + (size_t)MP * k) : double2{0.0, 0.0};
     }
+}
+__device__ __forceinline__ void bcr_mv_apply(const BcrSlice& t, int MP, const double* __restrict__ v, double& s0,
+                                             double& s1) {
+    const int w = threadIdx.x >> 6, cw = MP >> 4, k0 = cw * w;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        if (on[i]) {
+        if (i < cw) {
             const double vk = v[k0 + i];
-            s0 = __builtin_fma(m[i].x, vk, s0);
-            s1 = __builtin_fma(m[i].y, vk, s1);
+            s0 = __builtin_fma(t.m[i].x, vk, s0);
+            s1 = __builtin_fma(t.m[i].y, vk, s1);
         }
+}
+__device__ __forceinline__ void bcr_mv_partial(const double* __restrict__ Mx, int MP, const double* __restrict__ v,
+                                               int mode, double& s0, double& s1) {
+    BcrSlice t;
+    bcr_mv_load(Mx, MP, mode, t);
+    bcr_mv_apply(t, MP, v, s0, s1);
 }
 
 // partial sums -> red[w][row]; returns the row sum for tid < MP (all threads must call)
@@ -453,6 +510,7 @@ __global__ __launch_bounds__(BS_T) void bcr_fz_kernel(const double* __restrict__
 //   if a is eliminated at the next level (or is the last block): z_a = Linv_a r_a,
 //   and for the last block also p_0 = Linv_0^T z_0 (+= into accv).
 // grid (nsurv(l), O), block BS_T.
+template <bool PRE>  // PRE: request every block up front (fewer round trips, 2.5x the registers: small grids)
 __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict__ Linv, const double* __restrict__ LinvT,
                                                        const double* __restrict__ XAT, const double* __restrict__ XBT,
                                                        int M, int N, int MP, int s, int last,
@@ -470,6 +528,15 @@ __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict_
         zb[tid] = (hasB && tid < M) ? vec[(ib + a - s) * M + tid] : 0.0;
     }
     const double rold = (tid < M) ? va[tid] : 0.0;
+    const bool top = last != 0;                        // only a = 0 survives the last level
+    const bool next = top || ((t & 1) != 0);           // eliminated at level l+1
+    BcrSlice tA, tB, tL;
+    const bool dense = (band4 == nullptr);
+    if (PRE) {
+        if (dense && hasA) bcr_mv_load(XAT + (ib + a + s) * bsz, MP, 0, tA);
+        if (dense && hasB) bcr_mv_load(XBT + (ib + a - s) * bsz, MP, 0, tB);
+        if (next) bcr_mv_load(Linv + (ib + a) * bsz, MP, 1, tL);   // needed after the first product: in flight meanwhile
+    }
     __syncthreads();
     double s0 = 0.0, s1 = 0.0;
     double rnew;
@@ -485,12 +552,15 @@ __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict_
         }
         rnew = rold - t;
     } else {
-        if (hasA) bcr_mv_partial(XAT + (ib + a + s) * bsz, MP, za, 0, s0, s1);
-        if (hasB) bcr_mv_partial(XBT + (ib + a - s) * bsz, MP, zb, 0, s0, s1);
+        if (PRE) {
+            if (hasA) bcr_mv_apply(tA, MP, za, s0, s1);
+            if (hasB) bcr_mv_apply(tB, MP, zb, s0, s1);
+        } else {
+            if (hasA) bcr_mv_partial(XAT + (ib + a + s) * bsz, MP, za, 0, s0, s1);
+            if (hasB) bcr_mv_partial(XBT + (ib + a - s) * bsz, MP, zb, 0, s0, s1);
+        }
         rnew = rold - bcr_mv_reduce(red, MP, s0, s1);
     }
-    const bool top = last != 0;                        // only a = 0 survives the last level
-    const bool next = top || ((t & 1) != 0);           // eliminated at level l+1
     if (!next) {
         if (tid < M) va[tid] = rnew;
         return;
@@ -498,7 +568,10 @@ __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict_
     if (tid < MP) rn[tid] = (tid < M) ? rnew : 0.0;
     __syncthreads();
     s0 = 0.0; s1 = 0.0;
-    bcr_mv_partial(Linv + (ib + a) * bsz, MP, rn, 1, s0, s1);
+    if (PRE && top) bcr_mv_load(LinvT + (ib + a) * bsz, MP, 2, tA);   // last block: its transpose for the way back
+    if (!PRE) bcr_mv_load(Linv + (ib + a) * bsz, MP, 1, tL);
+    bcr_mv_apply(tL, MP, rn, s0, s1);
+    if (!PRE && top) bcr_mv_load(LinvT + (ib + a) * bsz, MP, 2, tA);
     const double z = bcr_mv_reduce(red, MP, s0, s1);
     if (!top) {
         if (tid < M) va[tid] = z;
@@ -507,7 +580,7 @@ __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict_
     if (tid < MP) za[tid] = (tid < M) ? z : 0.0;
     __syncthreads();
     s0 = 0.0; s1 = 0.0;
-    bcr_mv_partial(LinvT + (ib + a) * bsz, MP, za, 2, s0, s1);
+    bcr_mv_apply(tA, MP, za, s0, s1);
     const double p = bcr_mv_reduce(red, MP, s0, s1);
     if (tid < M) {
         va[tid] = p;
@@ -517,6 +590,7 @@ __global__ __launch_bounds__(BS_T) void bcr_fwd_kernel(const double* __restrict_
 
 // Backward step of level l for the eliminated blocks j = s + 2s*t:
 //   p_j = Linv_j^T (z_j - XA_j p_a - XB_j p_b)   (+= into accv).   grid (nelim(l), O), block BS_T.
+template <bool PRE>
 __global__ __launch_bounds__(BS_T) void bcr_bwd_kernel(const double* __restrict__ LinvT, const double* __restrict__ XA,
                                                        const double* __restrict__ XB, int M, int N, int MP, int s,
                                                        double* __restrict__ vec, double* __restrict__ accv) {
@@ -532,15 +606,27 @@ __global__ __launch_bounds__(BS_T) void bcr_bwd_kernel(const double* __restrict_
         pb[tid] = (hasB && tid < M) ? vec[(ib + b) * M + tid] : 0.0;
     }
     const double zj = (tid < M) ? vj[tid] : 0.0;
+    BcrSlice tA, tB, tL;
+    if (PRE) {
+        bcr_mv_load(XA + (ib + j) * bsz, MP, 0, tA);
+        if (hasB) bcr_mv_load(XB + (ib + j) * bsz, MP, 0, tB);
+        bcr_mv_load(LinvT + (ib + j) * bsz, MP, 2, tL);   // needed after the first product: in flight meanwhile
+    }
     __syncthreads();
     double s0 = 0.0, s1 = 0.0;
-    bcr_mv_partial(XA + (ib + j) * bsz, MP, pa, 0, s0, s1);
-    if (hasB) bcr_mv_partial(XB + (ib + j) * bsz, MP, pb, 0, s0, s1);
+    if (PRE) {
+        bcr_mv_apply(tA, MP, pa, s0, s1);
+        if (hasB) bcr_mv_apply(tB, MP, pb, s0, s1);
+    } else {
+        bcr_mv_partial(XA + (ib + j) * bsz, MP, pa, 0, s0, s1);
+        if (hasB) bcr_mv_partial(XB + (ib + j) * bsz, MP, pb, 0, s0, s1);
+    }
     const double acc = bcr_mv_reduce(red, MP, s0, s1);
     if (tid < MP) w[tid] = (tid < M) ? zj - acc : 0.0;
     __syncthreads();
     s0 = 0.0; s1 = 0.0;
-    bcr_mv_partial(LinvT + (ib + j) * bsz, MP, w, 2, s0, s1);
+    if (!PRE) bcr_mv_load(LinvT + (ib + j) * bsz, MP, 2, tL);
+    bcr_mv_apply(tL, MP, w, s0, s1);
     const double p = bcr_mv_reduce(red, MP, s0, s1);
     if (tid < M) {
         vj[tid] = p;
@@ -585,15 +671,25 @@ __device__ __forceinline__ void bcr0_thomas(const double* __restrict__ ell, cons
     }
 }
 
+// 1/x from v_rcp_f64 + two Newton steps (the pivots need not be correctly rounded; an IEEE divide
+// would put ~40 dependent instructions into every step of the sequential pivot recurrence)
+__device__ __forceinline__ double bcr0_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // pivots of the tridiagonal (d, e) by ONE lane (LDS arrays): delta_0 = d_0, ell_i = e_i/delta_i,
-// delta_{i+1} = d_{i+1} - ell_i e_i; then Q (M+1 entries).  Returns false on a non-positive pivot.
+// delta_{i+1} = d_{i+1} - ell_i e_i; then Q (M entries, Q_M = 0 implied).  Returns false on a
+// non-positive pivot.
 __device__ __forceinline__ bool bcr0_pivots(const double* __restrict__ d, const double* __restrict__ e,
                                             double* __restrict__ ell, double* __restrict__ invd,
                                             double* __restrict__ Q, int M) {
     double del = d[0];
     bool ok = del > 0.0;
     for (int i = 0; i < M; ++i) {
-        const double inv = 1.0 / del;
+        const double inv = bcr0_rcp(del);
         invd[i] = inv;
         if (i + 1 < M) {
             const double l = e[i] * inv;
@@ -605,7 +701,6 @@ __device__ __forceinline__ bool bcr0_pivots(const double* __restrict__ d, const 
         }
     }
     double q = 0.0;
-    Q[M] = 0.0;
     for (int i = M - 1; i >= 0; --i) {
         q = __builtin_fma(ell[i] * ell[i], q, invd[i]);
         Q[i] = q;
@@ -613,15 +708,55 @@ __device__ __forceinline__ bool bcr0_pivots(const double* __restrict__ d, const 
     return ok;
 }
 
-// Gram matrix of one family of columns (tail start s = x + off) into S (both triangles), threads x < M.
+// Pivots (ell, 1/delta) and Q of every odd block, once per factorisation.  grid (nelim(0), O), block 64.
+// Arrays [O][N][M], indexed by block.
+__global__ __launch_bounds__(64) void bcr0_pivot_kernel(const double* __restrict__ band4, int M, int N, int O,
+                                                        double* __restrict__ ell, double* __restrict__ invd,
+                                                        double* __restrict__ Qg, int* __restrict__ fail) {
+    __shared__ double d[BS_MP], e[BS_MP], l[BS_MP], iv[BS_MP], q[BS_MP];
+    const int j = 1 + 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const size_t tot = (size_t)M * N * O;
+    const size_t o = ((size_t)img * N + j) * M;
+    for (int i = tid; i < M; i += 64) {
+        d[i] = band4[o + i];
+        e[i] = (i + 1 < M) ? band4[tot + o + i] : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0 && !bcr0_pivots(d, e, l, iv, q, M) && fail[img] == 0) fail[img] = j + 1;
+    __syncthreads();
+    for (int i = tid; i < M; i += 64) { ell[o + i] = l[i]; invd[o + i] = iv[i]; Qg[o + i] = q[i]; }
+}
+
+// v(s0, s1) = prod_{m=s0}^{s1-1} (-ell_m), four independent partial products
+__device__ __forceinline__ double bcr0_vprod(const double* __restrict__ ell, int s0, int s1) {
+    double p0 = 1.0, p1 = 1.0, p2 = 1.0, p3 = 1.0;
+    int m = s0;
+    for (; m + 4 <= s1; m += 4) { p0 *= -ell[m]; p1 *= -ell[m + 1]; p2 *= -ell[m + 2]; p3 *= -ell[m + 3]; }
+    for (; m < s1; ++m) p0 *= -ell[m];
+    return (p0 * p1) * (p2 * p3);
+}
+
+constexpr int B0_T = 1024;
+constexpr int B0_SEG = 16;  // columns of one row handled by one thread
+
+// Gram matrix of one family of columns (tail start s = x + off) into S (both triangles).  Thread
+// (x = tid % 128, g = tid / 128) fills the entries (x, y), y in [16g, 16g+16), y >= x, and their mirrors.
 __device__ __forceinline__ void bcr0_gram(double* __restrict__ S, int ld, int M, int off, const double* __restrict__ eta,
                                           const double* __restrict__ om, const double* __restrict__ ell,
-                                          const double* __restrict__ invd, const double* __restrict__ Q, int x) {
+                                          const double* __restrict__ invd, const double* __restrict__ Q) {
+    const int x = threadIdx.x & 127, g = threadIdx.x >> 7;
+    if (x >= M) return;
     const int s = x + off;
     const double ex = eta[x], ox = om[x];
-    S[x + ld * x] = ((s >= 1) ? invd[s - 1] * ex * ex : 0.0) + ((s < M) ? ox * ox * Q[s] : 0.0);
-    double v = 1.0;  // v(s, s'-1)
-    for (int y = x + 1; y < M; ++y) {
+    int y0 = B0_SEG * g, y1 = y0 + B0_SEG;
+    if (y1 > M) y1 = M;
+    if (y0 <= x && x < y1) {
+        S[x + ld * x] = ((s >= 1) ? invd[s - 1] * ex * ex : 0.0) + ((s < M) ? ox * ox * Q[s] : 0.0);
+        y0 = x + 1;
+    }
+    if (y0 <= x || y0 >= y1) return;
+    double v = bcr0_vprod(ell, s, y0 + off - 1);  // v(s, s'-1) for s' = y0 + off
+    for (int y = y0; y < y1; ++y) {
         const int sp = y + off;          // s' - 1 >= s, s' - 1 <= M - 1
         const double head = invd[sp - 1] * eta[y] * (ox * v);
         v *= -ell[sp - 1];               // v(s, s')
@@ -632,63 +767,80 @@ __device__ __forceinline__ void bcr0_gram(double* __restrict__ S, int ld, int M,
     }
 }
 
-// Cross Gram matrix S(r, c) = <XB column r, XA column c> (XB: s = r+1; XA: s = c), threads r < M.
+// Cross Gram matrix S(r, c) = <XB column r, XA column c> (XB: s = r+1; XA: s = c).  Thread
+// (r = tid % 128, g = tid / 128) fills the columns c in [16g, 16g+16).
 __device__ __forceinline__ void bcr0_cross(double* __restrict__ S, int ld, int M, const double* __restrict__ etaB,
                                            const double* __restrict__ omB, const double* __restrict__ etaA,
                                            const double* __restrict__ omA, const double* __restrict__ ell,
-                                           const double* __restrict__ invd, const double* __restrict__ Q, int r) {
+                                           const double* __restrict__ invd, const double* __restrict__ Q) {
+    const int r = threadIdx.x & 127, g = threadIdx.x >> 7;
+    if (r >= M) return;
     const int sb = r + 1;
     const double eb = etaB[r], ob = omB[r];
+    int c0 = B0_SEG * g, c1 = c0 + B0_SEG;
+    if (c1 > M) c1 = M;
+    if (c0 >= c1) return;
     // columns c >= r+1: the XB column starts first (s = sb <= s' = c)
-    if (sb < M) {
-        S[r + ld * sb] = invd[sb - 1] * eb * etaA[sb] + ob * omA[sb] * Q[sb];
-        double v = 1.0;  // v(sb, c-1)
-        for (int c = sb + 1; c < M; ++c) {
-            const double head = invd[c - 1] * etaA[c] * (ob * v);
-            v *= -ell[c - 1];
-            S[r + ld * c] = head + (ob * omA[c]) * v * Q[c];
+    {
+        int c = (c0 > sb) ? c0 : sb;
+        if (c < c1) {
+            double v = 1.0;  // v(sb, c-1)
+            if (c == sb) {
+                S[r + ld * sb] = invd[sb - 1] * eb * etaA[sb] + ob * omA[sb] * Q[sb];
+                ++c;
+            } else {
+                v = bcr0_vprod(ell, sb, c - 1);
+            }
+            for (; c < c1; ++c) {
+                const double head = invd[c - 1] * etaA[c] * (ob * v);
+                v *= -ell[c - 1];
+                S[r + ld * c] = head + (ob * omA[c]) * v * Q[c];
+            }
         }
     }
     // columns c <= r: the XA column starts first (s = c < s' = sb); head of the XB column at index r
-    double v = 1.0;      // v(c, r)
-    for (int c = r; c >= 0; --c) {
-        const double head = invd[r] * eb * (omA[c] * v);
-        const double tail = (sb < M) ? (omA[c] * ob) * (v * -ell[r]) * Q[sb] : 0.0;
-        S[r + ld * c] = head + tail;
-        if (c >= 1) v *= -ell[c - 1];
+    {
+        int c = (c1 - 1 < r) ? c1 - 1 : r;
+        if (c >= c0) {
+            double v = bcr0_vprod(ell, c, r);      // v(c, r)
+            const double qt = (sb < M) ? -ell[r] * Q[sb] : 0.0;
+            for (; c >= c0; --c) {
+                S[r + ld * c] = invd[r] * eb * (omA[c] * v) + (omA[c] * ob) * (v * qt);
+                if (c >= 1) v *= -ell[c - 1];
+            }
+        }
     }
 }
 
-constexpr int B0_T = 1024;
-
 // Level-0 Schur complements.  grid (nsurv(0), O), block B0_T, dynamic LDS bcr0_schur_lds(MP).
-// Writes the dense D_a (Li slot) and C'_a (C slot) of every even block a and the pivots of block a+1.
+// Writes the dense D_a (Li slot) and C'_a (C slot) of every even block a.
 __global__ __launch_bounds__(B0_T) void bcr0_schur_kernel(const double* __restrict__ band4, int M, int N, int O, int MP,
                                                           double* __restrict__ D, double* __restrict__ C,
-                                                          double* __restrict__ ell, double* __restrict__ invd,
-                                                          int* __restrict__ fail) {
+                                                          const double* __restrict__ ell, const double* __restrict__ invd,
+                                                          const double* __restrict__ Qg) {
     extern __shared__ double S[];
     const int ld = MP + 1;
     double* co = S + (size_t)ld * MP;
     const int MQ = MP + 1;
-    // per side (0 = block a-1, 1 = block a+1): d, e, ell, invd, Q
-    double *dd[2] = {co, co + MQ}, *ee[2] = {co + 2 * MQ, co + 3 * MQ};
-    double *ll[2] = {co + 4 * MQ, co + 5 * MQ}, *iv[2] = {co + 6 * MQ, co + 7 * MQ}, *QQ[2] = {co + 8 * MQ, co + 9 * MQ};
+    // per side (0 = block a-1, 1 = block a+1): ell, invd, Q
+    double *ll[2] = {co, co + MQ}, *iv[2] = {co + 2 * MQ, co + 3 * MQ}, *QQ[2] = {co + 4 * MQ, co + 5 * MQ};
     // couplings: g/h of C_{a-1}, C_a, C_{a+1};  omegas of the three column families
-    double *gl = co + 10 * MQ, *hl = co + 11 * MQ, *gu = co + 12 * MQ, *hu = co + 13 * MQ, *g2 = co + 14 * MQ,
-           *h2 = co + 15 * MQ, *oBl = co + 16 * MQ, *oA = co + 17 * MQ, *oB2 = co + 18 * MQ;
+    double *gl = co + 6 * MQ, *hl = co + 7 * MQ, *gu = co + 8 * MQ, *hu = co + 9 * MQ, *g2 = co + 10 * MQ,
+           *h2 = co + 11 * MQ, *oBl = co + 12 * MQ, *oA = co + 13 * MQ, *oB2 = co + 14 * MQ;
     const int a = 2 * (int)blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const size_t npx = (size_t)M * N, tot = npx * O;
-    const size_t qa = (size_t)img * npx + (size_t)a * M;   // first pixel of block a
+    const size_t qa = (size_t)img * npx + (size_t)a * M;   // first pixel of block a (== its offset in the pivot arrays)
     const bool has[2] = {a >= 1, a + 1 < N};
     const bool hasC2 = a + 2 < N;
-    if (tid < MP) {
+    if (tid <= MP) {
         const int i = tid;
         const bool in = i < M;
-        dd[0][i] = (has[0] && in) ? band4[qa - M + i] : 1.0;
-        ee[0][i] = (has[0] && i + 1 < M) ? band4[tot + qa - M + i] : 0.0;
-        dd[1][i] = (has[1] && in) ? band4[qa + M + i] : 1.0;
-        ee[1][i] = (has[1] && i + 1 < M) ? band4[tot + qa + M + i] : 0.0;
+        ll[0][i] = (has[0] && in) ? ell[qa - M + i] : 0.0;
+        iv[0][i] = (has[0] && in) ? invd[qa - M + i] : 1.0;
+        QQ[0][i] = (has[0] && in) ? Qg[qa - M + i] : 0.0;
+        ll[1][i] = (has[1] && in) ? ell[qa + M + i] : 0.0;
+        iv[1][i] = (has[1] && in) ? invd[qa + M + i] : 1.0;
+        QQ[1][i] = (has[1] && in) ? Qg[qa + M + i] : 0.0;
         gl[i] = (has[0] && in) ? band4[3 * tot + qa - M + i] : 0.0;             // C_{a-1}(r, r)
         hl[i] = (has[0] && in && i >= 1) ? band4[2 * tot + qa - M + i] : 0.0;   // C_{a-1}(c-1, c)
         gu[i] = (has[1] && in) ? band4[3 * tot + qa + i] : 0.0;                 // C_a
@@ -697,18 +849,8 @@ __global__ __launch_bounds__(B0_T) void bcr0_schur_kernel(const double* __restri
         h2[i] = (hasC2 && in && i >= 1) ? band4[2 * tot + qa + M + i] : 0.0;
     }
     __syncthreads();
-    if ((tid == 0 && has[0]) || (tid == 64 && has[1])) {   // two waves, one lane each
-        const int sd = tid >> 6;
-        if (!bcr0_pivots(dd[sd], ee[sd], ll[sd], iv[sd], QQ[sd], M) && fail[img] == 0) fail[img] = a + (sd ? 2 : 0);
-    }
-    __syncthreads();
     if (tid < M) {
         const int i = tid;
-        if (has[1]) {   // the pivots of block a+1 serve the substitutions
-            const size_t o = ((size_t)img * N + a + 1) * M + i;
-            ell[o] = ll[1][i];
-            invd[o] = iv[1][i];
-        }
         oBl[i] = (i + 1 < M) ? hl[i + 1] - ll[0][i] * gl[i] : 0.0;
         oA[i] = gu[i] - ((i >= 1) ? ll[1][i - 1] * hu[i] : 0.0);
         oB2[i] = (i + 1 < M) ? h2[i + 1] - ll[1][i] * g2[i] : 0.0;
@@ -724,33 +866,47 @@ __global__ __launch_bounds__(B0_T) void bcr0_schur_kernel(const double* __restri
         }
         return (r == c) ? 1.0 : 0.0;
     };
-    // the contributions travel through global memory (each thread re-reads its own entries)
-    if (has[0]) {   // XB'^T XB' of block a-1
-        if (tid < M) bcr0_gram(S, ld, M, 1, gl, oBl, ll[0], iv[0], QQ[0], tid);
-        __syncthreads();
-        for (int e = tid; e < MP * MP; e += B0_T) {
-            const int r = e % MP, c = e / MP;
-            D[bo + e] = tridiag(r, c) - ((r < M && c < M) ? S[r + ld * c] : 0.0);
-        }
-        __syncthreads();
-    } else {
-        for (int e = tid; e < MP * MP; e += B0_T) D[bo + e] = tridiag(e % MP, e / MP);
+    // the thread's entries e = tid + B0_T*i of D_a: tridiagonal part minus the two Gram matrices
+    constexpr int NE = BS_MP * BS_MP / B0_T;
+    double acc[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + B0_T * i;
+        acc[i] = (e < MP * MP) ? tridiag(e % MP, e / MP) : 0.0;
     }
-    if (has[1]) {   // XA^T XA of block a+1, then the new coupling -XB^T XA
-        if (tid < M) bcr0_gram(S, ld, M, 0, hu, oA, ll[1], iv[1], QQ[1], tid);
+    if (has[0]) {   // XB'^T XB' of block a-1
+        bcr0_gram(S, ld, M, 1, gl, oBl, ll[0], iv[0], QQ[0]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + B0_T * i;
+            const int r = e % MP, c = e / MP;
+            if (e < MP * MP && r < M && c < M) acc[i] -= S[r + ld * c];
+        }
+        __syncthreads();
+    }
+    if (has[1]) {   // XA^T XA of block a+1
+        bcr0_gram(S, ld, M, 0, hu, oA, ll[1], iv[1], QQ[1]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + B0_T * i;
+            const int r = e % MP, c = e / MP;
+            if (e < MP * MP && r < M && c < M) acc[i] -= S[r + ld * c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + B0_T * i;
+        if (e < MP * MP) D[bo + e] = acc[i];
+    }
+    if (hasC2) {    // the new coupling -XB^T XA
+        bcr0_cross(S, ld, M, g2, oB2, hu, oA, ll[1], iv[1], QQ[1]);
         __syncthreads();
         for (int e = tid; e < MP * MP; e += B0_T) {
             const int r = e % MP, c = e / MP;
-            if (r < M && c < M) D[bo + e] -= S[r + ld * c];
-        }
-        __syncthreads();
-        if (hasC2) {
-            if (tid < M) bcr0_cross(S, ld, M, g2, oB2, hu, oA, ll[1], iv[1], QQ[1], tid);
-            __syncthreads();
-            for (int e = tid; e < MP * MP; e += B0_T) {
-                const int r = e % MP, c = e / MP;
-                C[bo + e] = (r < M && c < M) ? -S[r + ld * c] : 0.0;
-            }
+            C[bo + e] = (r < M && c < M) ? -S[r + ld * c] : 0.0;
         }
     }
 }
@@ -808,16 +964,16 @@ __global__ __launch_bounds__(64) void bcr0_bwd_kernel(const double* __restrict__
 // ---- host-side launch sequences -------------------------------------------------------------------
 struct BcrArrays {
     double *Li, *LiT, *C, *XA, *XAT, *XB, *XBT;  // [O][N][MP*MP] each
-    double *ell, *invd;                            // pivots of the odd blocks, [O][N][M] each
-    static size_t doubles(int M, int N, int O, int MP) { return 7 * (size_t)O * N * MP * MP + 2 * (size_t)O * N * M; }
+    double *ell, *invd, *Q;                        // pivots of the odd blocks, [O][N][M] each
+    static size_t doubles(int M, int N, int O, int MP) { return 7 * (size_t)O * N * MP * MP + 3 * (size_t)O * N * M; }
     static BcrArrays carve(double* base, int M, int N, int O, int MP) {
         const size_t a = (size_t)O * N * MP * MP;
         return BcrArrays{base, base + a, base + 2 * a, base + 3 * a, base + 4 * a, base + 5 * a, base + 6 * a,
-                         base + 7 * a, base + 7 * a + (size_t)O * N * M};
+                         base + 7 * a, base + 7 * a + (size_t)O * N * M, base + 7 * a + 2 * (size_t)O * N * M};
     }
 };
 inline size_t bcr_potrf_lds(int MP) { return (size_t)(MP + 1) * MP * sizeof(double); }
-inline size_t bcr0_schur_lds(int MP) { return ((size_t)(MP + 1) * MP + 19 * (size_t)(MP + 1)) * sizeof(double); }
+inline size_t bcr0_schur_lds(int MP) { return ((size_t)(MP + 1) * MP + 15 * (size_t)(MP + 1)) * sizeof(double); }
 
 // Dense levels l >= l0 of the factorisation of the block tridiagonal matrices held in
 // (B.Li = diagonal blocks, B.C = couplings at stride 2^l0), then the last block.
@@ -827,10 +983,10 @@ inline void bcr_factor_launch(hipStream_t st, const BcrArrays& B, int N, int O, 
     for (int l = l0; l < BL; ++l) {
         const int s = 1 << l, ne = bcr_nelim(N, l), ns = bcr_nsurv(N, l);
         hipLaunchKernelGGL(bcr_potrf_kernel, dim3(ne, O), dim3(BCR_PT), bcr_potrf_lds(MP), st, B.Li, B.LiT, N, MP, s, d_fail);
-        hipLaunchKernelGGL(bcr_x_kernel, dim3(nt * nt, 2 * ne, O), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N,
-                           MP, s);
-        hipLaunchKernelGGL(bcr_upd_kernel, dim3(nt * nt, 2 * ns, O), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT,
-                           N, MP, s);
+        hipLaunchKernelGGL(bcr_x_kernel, dim3(bg_grid(2u * ne * O, nt)), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT,
+                           N, O, MP, s);
+        hipLaunchKernelGGL(bcr_upd_kernel, dim3(bg_grid(2u * ns * O, nt)), dim3(BG_T), 0, st, B.Li, B.C, B.XA, B.XAT, B.XB,
+                           B.XBT, N, O, MP, s);
     }
     hipLaunchKernelGGL(bcr_potrf_kernel, dim3(1, O), dim3(BCR_PT), bcr_potrf_lds(MP), st, B.Li, B.LiT, N, MP, 0, d_fail);
 }
@@ -838,8 +994,9 @@ inline void bcr_factor_launch(hipStream_t st, const BcrArrays& B, int N, int O, 
 // Assembled diagonals -> factorisation: level 0 in operator form, the rest dense.
 inline void bcr_factor_band4_launch(hipStream_t st, const BcrArrays& B, const double* band4, int M, int N, int O, int MP,
                                     int* d_fail) {
+    hipLaunchKernelGGL(bcr0_pivot_kernel, dim3(bcr_nelim(N, 0), O), dim3(64), 0, st, band4, M, N, O, B.ell, B.invd, B.Q, d_fail);
     hipLaunchKernelGGL(bcr0_schur_kernel, dim3(bcr_nsurv(N, 0), O), dim3(B0_T), bcr0_schur_lds(MP), st, band4, M, N, O, MP,
-                       B.Li, B.C, B.ell, B.invd, d_fail);
+                       B.Li, B.C, B.ell, B.invd, B.Q);
     bcr_factor_launch(st, B, N, O, MP, d_fail, 1);
 }
 
@@ -852,18 +1009,30 @@ inline void bcr_solve_launch(hipStream_t st, const BcrArrays& B, int M, int N, i
         hipLaunchKernelGGL(bcr0_y_kernel, dim3(bcr_nelim(N, 0), O), dim3(64), 0, st, B.ell, B.invd, M, N, vec);
     else
         hipLaunchKernelGGL(bcr_fz_kernel, dim3(bcr_nelim(N, 0), O), dim3(BS_T), 0, st, B.Li, M, N, MP, vec);
-    for (int l = 0; l < BL; ++l)
-        hipLaunchKernelGGL(bcr_fwd_kernel, dim3(bcr_nsurv(N, l), O), dim3(BS_T), 0, st, B.Li, B.LiT, B.XAT, B.XBT, M, N, MP,
-                           1 << l, (l == BL - 1) ? 1 : 0, vec, accv, (l == 0) ? band4 : (const double*)nullptr, O);
-    for (int l = BL - 1; l >= 1; --l)
-        hipLaunchKernelGGL(bcr_bwd_kernel, dim3(bcr_nelim(N, l), O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1 << l,
-                           vec, accv);
+    // grids of at most one workgroup per CU pair: latency bound -> prefetching instance
+    auto small = [&](int blocks) { return (size_t)blocks * O <= 192; };
+    for (int l = 0; l < BL; ++l) {
+        const int ns = bcr_nsurv(N, l);
+        if (small(ns))
+            hipLaunchKernelGGL(bcr_fwd_kernel<true>, dim3(ns, O), dim3(BS_T), 0, st, B.Li, B.LiT, B.XAT, B.XBT, M, N, MP, 1 << l,
+                               (l == BL - 1) ? 1 : 0, vec, accv, (l == 0) ? band4 : (const double*)nullptr, O);
+        else
+            hipLaunchKernelGGL(bcr_fwd_kernel<false>, dim3(ns, O), dim3(BS_T), 0, st, B.Li, B.LiT, B.XAT, B.XBT, M, N, MP, 1 << l,
+                               (l == BL - 1) ? 1 : 0, vec, accv, (l == 0) ? band4 : (const double*)nullptr, O);
+    }
+    for (int l = BL - 1; l >= 1; --l) {
+        const int ne = bcr_nelim(N, l);
+        if (small(ne))
+            hipLaunchKernelGGL(bcr_bwd_kernel<true>, dim3(ne, O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1 << l, vec, accv);
+        else
+            hipLaunchKernelGGL(bcr_bwd_kernel<false>, dim3(ne, O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1 << l, vec, accv);
+    }
     if (band4)
         hipLaunchKernelGGL(bcr0_bwd_kernel, dim3(bcr_nelim(N, 0), O), dim3(64), 0, st, band4, B.ell, B.invd, M, N, O, vec,
                            accv);
     else
-        hipLaunchKernelGGL(bcr_bwd_kernel, dim3(bcr_nelim(N, 0), O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1, vec,
-                           accv);
+        hipLaunchKernelGGL(bcr_bwd_kernel<false>, dim3(bcr_nelim(N, 0), O), dim3(BS_T), 0, st, B.LiT, B.XA, B.XB, M, N, MP, 1,
+                           vec, accv);
 }
 
 }  // namespace bpltv

@@ -81,7 +81,7 @@ static void test_gemm(int MP) {
     CK(hipMemcpy(d, h.data(), 7 * arr * 8, hipMemcpyHostToDevice));
     BcrArrays B = BcrArrays::carve(d, MP, N, O, MP);
     const unsigned nt = (MP + 63) / 64;
-    hipLaunchKernelGGL(bcr_x_kernel, dim3(nt * nt, 2 * bcr_nelim(N, 0), O), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, MP, s);
+    hipLaunchKernelGGL(bcr_x_kernel, dim3(bg_grid(2u * bcr_nelim(N, 0) * O, nt)), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, O, MP, s);
     CK(hipDeviceSynchronize());
     std::vector<double> g(7 * arr);
     CK(hipMemcpy(g.data(), d, 7 * arr * 8, hipMemcpyDeviceToHost));
@@ -104,7 +104,7 @@ static void test_gemm(int MP) {
     snprintf(name, sizeof name, "x kernel MP=%d  XB", MP); report(name, eB, 1e-12 * MP);
     snprintf(name, sizeof name, "x kernel MP=%d  transposes", MP); report(name, eT, 0.0);
     // update kernel on the device's own X
-    hipLaunchKernelGGL(bcr_upd_kernel, dim3(nt * nt, 2 * bcr_nsurv(N, 0), O), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, MP, s);
+    hipLaunchKernelGGL(bcr_upd_kernel, dim3(bg_grid(2u * bcr_nsurv(N, 0) * O, nt)), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, O, MP, s);
     CK(hipDeviceSynchronize());
     std::vector<double> u(7 * arr);
     CK(hipMemcpy(u.data(), d, 7 * arr * 8, hipMemcpyDeviceToHost));
