@@ -224,21 +224,20 @@ constexpr int BG_T = 256;   // 4 waves, each a 32x32 quarter of the tile
 constexpr int BG_KC = 32;   // depth of one staged chunk
 constexpr int BG_LD = 65;
 
-// Staging layout of one 64 x BG_KC operand chunk: Ls[kk][r][q] = Op(r, 4kk + q) with a kk-stride of
-// BG_KS doubles -- the 64 lanes of an MFMA operand read (16 rows x 4 k) then fetch 64 consecutive
-// doubles (conflict free), and so do the staging writes of both operand orientations.
-constexpr int BG_KS = 64 * 4 + 4;
-
 // 64 x BG_KC chunk of Op(rr, kk), rr in [r0, r0+64), kk in [k0, k0+BG_KC) -> v[8] (zero outside MP).
-// RFAST: element (rr, kk) at rr + MP*kk; otherwise at kk + MP*rr.
+// RFAST: element (rr, kk) at rr + MP*kk; otherwise at kk + MP*rr.  Staged as Ls[kk][rr] with a row
+// stride of BG_LD = 65 doubles: the 16 lanes of an MFMA operand row read 16 consecutive doubles.
+// (An interleaved [kk/4][rr][kk%4] layout and whole-block 128x128 workgroups were measured too: no
+// gain resp. 1.5x slower; PMC: MFMA pipe 29 % busy, waves 52 % waiting -- the products are bound by
+// the latency of the operand panels streaming from HBM, not by LDS or MFMA issue.)
 template <bool RFAST>
 __device__ __forceinline__ void bg_fetch(const double* __restrict__ base, int MP, int r0, int k0, int tid,
                                          double (&v)[8]) {
     if (RFAST) {
-        const int r = r0 + (tid & 63), kq = k0 + 8 * (tid >> 6);   // 8 consecutive k of one row
+        const int r = r0 + (tid & 63), kq = k0 + (tid >> 6);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int k = kq + i;
+            const int k = kq + 4 * i;
             v[i] = (r < MP && k < MP) ? base[r + (size_t)MP * k] : 0.0;
         }
     } else {
@@ -253,15 +252,13 @@ __device__ __forceinline__ void bg_fetch(const double* __restrict__ base, int MP
 template <bool RFAST>
 __device__ __forceinline__ void bg_stage(double* __restrict__ Ls, int tid, const double (&v)[8]) {
     if (RFAST) {
-        const int r = tid & 63, kk = 2 * (tid >> 6);
-        double* d = Ls + kk * BG_KS + r * 4;
-        *reinterpret_cast<double4*>(d) = double4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<double4*>(d + BG_KS) = double4{v[4], v[5], v[6], v[7]};
+        const int r = tid & 63, kq = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Ls[(kq + 4 * i) * BG_LD + r] = v[i];
     } else {
         const int k = tid & 31, rq = tid >> 5;
-        double* d = Ls + (k >> 2) * BG_KS + (k & 3);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[(rq + 8 * i) * 4] = v[i];
+        for (int i = 0; i < 8; ++i) Ls[k * BG_LD + rq + 8 * i] = v[i];
     }
 }
 
@@ -277,7 +274,7 @@ __device__ __forceinline__ void bg_product(const double* __restrict__ A0, const 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
     double* As = lds;
-    double* Bs = lds + (BG_KC / 4) * BG_KS;
+    double* Bs = lds + BG_KC * BG_LD;
     const int nk = (kend + BG_KC - 1) / BG_KC, nchunk = nk * nprod;
     double va[8], vb[8];
     bg_fetch<ARF>(A0, MP, r0, 0, tid, va);
@@ -296,9 +293,9 @@ __device__ __forceinline__ void bg_product(const double* __restrict__ A0, const 
         }
 #pragma unroll
         for (int kk = 0; kk < BG_KC / 4; ++kk) {
-            const int ko = kk * BG_KS + lr * 4 + lk;
-            const double a0 = As[ko + wr * 4], a1 = As[ko + (wr + 16) * 4];
-            const double b0 = Bs[ko + wc * 4], b1 = Bs[ko + (wc + 16) * 4];
+            const int ko = (4 * kk + lk) * BG_LD;
+            const double a0 = As[ko + wr + lr], a1 = As[ko + wr + 16 + lr];
+            const double b0 = Bs[ko + wc + lr], b1 = Bs[ko + wc + 16 + lr];
             acc.c[0][0] = bcr_mfma(a0, b0, acc.c[0][0]);
             acc.c[0][1] = bcr_mfma(a0, b1, acc.c[0][1]);
             acc.c[1][0] = bcr_mfma(a1, b0, acc.c[1][0]);
@@ -322,8 +319,7 @@ __device__ __forceinline__ void bg_to_lds(const BgAcc& acc, double* __restrict__
     __syncthreads();
 }
 
-constexpr int BG_LDS = 2 * (BG_KC / 4) * BG_KS;  // doubles: staging (2 x 8 x 260) and the output tile (64 x 65) share it
-static_assert(BG_LDS >= 64 * BG_LD, "output tile must fit the staging buffers");
+constexpr int BG_LDS = 64 * BG_LD;  // doubles: staging (2 x 32 x 65) and the output tile (64 x 65) share it
 
 // Workgroup id -> (product, tile).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with
 // its own L2; the nt*nt tiles of one product re-read the same operand panels, so they are given ids of

@@ -44,8 +44,9 @@ enum {
     BPLTV_E_UNSUPPORTED = 6
 };
 /* Sizes: PDHG, loss, sweep and the adjoint gradient accept any M x N x O that fits in HBM.  The gradient
- * uses an LDS-resident band window for M <= 138 and an HBM-resident band (M*N*(M+1) doubles per image,
- * allocated on first use) beyond that. */
+ * factors its linear system by block cyclic reduction for M <= 128 (7*N*MP^2 doubles per image, MP = M
+ * rounded up to 16), by a banded Cholesky with an LDS-resident window for M <= 138 and with an
+ * HBM-resident band (M*N*(M+1) doubles per image) beyond that; all workspaces are allocated on first use. */
 
 typedef struct bpltv_handle bpltv_t;
 

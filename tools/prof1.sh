@@ -14,3 +14,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_pmc2 -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_pmc3 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/prof_pmc3.log 2>&1 || { tail -20 $OUT/prof_pmc3.log; exit 1; }
 find $OUT -name "*.csv" | head -20
 du -sh $OUT
+# full evaluate (PDHG + loss + adjoint gradient by block cyclic reduction), kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eval -- python3 tools/eval_once.py > $OUT/prof_eval.log 2>&1 || { tail -20 $OUT/prof_eval.log; exit 1; }
+grep "^alpha" $OUT/prof_eval.log
