@@ -41,7 +41,9 @@ class BpltvStats(C.Structure):
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm"}.get(self.reserved[0], "")
+        return d
 
 
 # every symbol include/bpltv.h declares: name -> (restype, argtypes)

@@ -771,11 +771,12 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
+    h->st.reserved[0] = use_bcr ? 2 : (h->adj_hbm ? 3 : 1);
     double worst = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
-            return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at column %d of image %d",
-                           fail[k] - 1, k);
+            return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at %s %d of image %d",
+                           use_bcr ? "block" : "column", fail[k] - 1, k);
         const double r = std::sqrt(resn[2 * k]) / (resn[2 * k + 1] > 0 ? std::sqrt(resn[2 * k + 1]) : 1.0);
         if (r > worst) worst = r;
     }

@@ -91,7 +91,8 @@ typedef struct bpltv_stats {
     double last_gap;           /* max over images of the duality gap if it was computed, else -1  */
     double adjoint_residual;   /* max over images of ||rhs - A p|| / ||rhs|| after refinement     */
     int reg_gradient_used;     /* 1 if the last evaluate took the gradient_reg branch             */
-    int reserved[7];
+    int reserved[7];           /* [0] factorisation of the last adjoint solve: 1 banded Cholesky (LDS window),
+                                  2 block cyclic reduction, 3 banded Cholesky (HBM band)              */
 } bpltv_stats_t;
 
 /* Fill *p with the reference defaults (src/TVLearningFunctionVec.jl:33-43, delta_t 1e-6). */

@@ -356,6 +356,7 @@ def test_both_adjoint_factorisations_agree(gpu_solver_cls, oracle, shape):
         res = {}
         for meth in ("band", "bcr"):
             _, _, g = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method=meth)
+            assert s.stats()["adjoint_method"] == meth
             _, _, r = s.evaluate(alpha, 0.0, maxiter=400, adjoint_method=meth)
             assert np.allclose(g, g0, rtol=2e-6, atol=1e-9), (meth, shape)
             assert np.allclose(r, r0, rtol=1e-7, atol=1e-11), (meth, shape)
@@ -376,7 +377,7 @@ def test_bcr_is_refused_where_it_does_not_apply(gpu_solver_cls):
         s.evaluate(0.1, 0.1, maxiter=50, adjoint_method="bcr")
     assert e.value.code == 6
     u, c, g = s.evaluate(0.1, 0.1, maxiter=50)   # automatic choice: banded Cholesky
-    assert np.isfinite(g)
+    assert np.isfinite(g) and s.stats()["adjoint_method"] == "band"
     s.close()
 
 
