@@ -220,6 +220,19 @@ def main():
                          "bytes_per_px_iter": bytes_px},
             "pdhg_event_ms_per_step": ev_ms / args.steps,
         }
+        if world == 1 and not args.evaluate and M * N * O_local <= 16 * 128 * 128:
+            # outside the timed region: one full learning-function evaluation on the same resident batch
+            # (PDHG + loss + adjoint gradient), the unit of work of the outer trust-region loop
+            tt, pm, am = [], [], []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                solver.evaluate_device(alpha, 0.1, part.data_ptr(), **kw)
+                torch.cuda.synchronize()
+                tt.append(1e3 * (time.perf_counter() - t1))
+                s3 = solver.stats(); pm.append(s3["pdhg_ms"]); am.append(s3["adjoint_ms"])
+            out["learning_function"] = {"evaluate_ms": min(tt), "pdhg_ms": min(pm), "adjoint_ms": min(am),
+                                        "adjoint_method": s3["adjoint_method"], "adjoint_residual": s3["adjoint_residual"],
+                                        "note": "tv_op_learning_function on the same batch, best of 3, not part of `value`"}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             from oracle import c_oracle as co
             cpu_iters = args.cpu_iters or min(args.iters, 5000 if M * N * args.images <= 200000 else 20)

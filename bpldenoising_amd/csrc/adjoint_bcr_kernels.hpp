@@ -33,6 +33,13 @@ namespace bpltv {
 
 typedef double bcr_d4 __attribute__((ext_vector_type(4)));
 
+#ifdef BCR_DBG   // timing experiments of tools/bcr_unit.hip only (results are wrong when set)
+__device__ int bcr_dbg = 0;   // 1 skip operand global loads, 2 skip MFMAs, 4 skip LDS staging, 8 skip the output phase
+#define BCR_DBG_ON(bit) (bcr_dbg & (bit))
+#else
+#define BCR_DBG_ON(bit) false
+#endif
+
 __host__ __device__ inline int bcr_levels(int N) {
     int L = 0;
     while ((1 << L) < N) ++L;
@@ -281,16 +288,19 @@ __device__ __forceinline__ void bg_product(const double* __restrict__ A0, const 
     bg_fetch<BCF>(B0, MP, c0, 0, tid, vb);
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // the previous chunk has been consumed
-        bg_stage<ARF>(As, tid, va);
-        bg_stage<BCF>(Bs, tid, vb);
+        if (!BCR_DBG_ON(4)) {
+            bg_stage<ARF>(As, tid, va);
+            bg_stage<BCF>(Bs, tid, vb);
+        }
         __syncthreads();
-        if (ch + 1 < nchunk) {
+        if (ch + 1 < nchunk && !BCR_DBG_ON(1)) {
             const int nx = ch + 1;
             const bool second = nx >= nk;
             const int k0 = (second ? nx - nk : nx) * BG_KC;
             bg_fetch<ARF>(second ? A1 : A0, MP, r0, k0, tid, va);
             bg_fetch<BCF>(second ? B1 : B0, MP, c0, k0, tid, vb);
         }
+        if (BCR_DBG_ON(2)) continue;
 #pragma unroll
         for (int kk = 0; kk < BG_KC / 4; ++kk) {
             const int ko = (4 * kk + lk) * BG_LD;
@@ -414,6 +424,10 @@ __global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, d
         bg_product<true, false>(XBT + (ib + a + s) * bsz, XA + (ib + a + s) * bsz, nullptr, nullptr, 1, MP, r0, c0, MP, lds,
                                 acc);
         Out = C + (ib + a) * bsz;
+    }
+    if (BCR_DBG_ON(8)) {
+        if (acc.c[0][0][0] == 12345.678) Out[0] = 0.0;
+        return;
     }
     bg_to_lds(acc, lds);
     const int tid = threadIdx.x;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define BCR_DBG 1
 #include "adjoint_bcr_kernels.hpp"
 
 using namespace bpltv;
@@ -214,7 +215,37 @@ static void test_solve(int M, int N, int O, bool op0) {
     CK(hipFree(d)); CK(hipFree(dv)); CK(hipFree(da)); CK(hipFree(dfail)); CK(hipFree(db4));
 }
 
-int main() {
+// timing of the product kernels on the level-1 shape of a 10 x 128^2 batch (values are irrelevant)
+static void bench_products() {
+    const int M = 128, N = 128, O = 10, MP = 128, s = 2, l = 1;
+    const size_t nd = BcrArrays::doubles(M, N, O, MP);
+    double* d;
+    CK(hipMalloc(&d, nd * 8));
+    CK(hipMemset(d, 0, nd * 8));
+    BcrArrays B = BcrArrays::carve(d, M, N, O, MP);
+    const unsigned nt = 2;
+    const int ne = bcr_nelim(N, l), ns = bcr_nsurv(N, l);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double fl_x = 2.0 * ne * O * 2.0 * 128 * 128 * 128 * 0.75, fl_u = (2.0 * ns - 1 + ne) * O * 2.0 * 128 * 128 * 128;
+    for (int dbg : {0, 1, 2, 4, 8, 3, 6, 7, 15}) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bcr_dbg), &dbg, sizeof(int)));
+        float tx = 0, tu = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(bcr_x_kernel, dim3(bg_grid(2u * ne * O, nt)), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, O, MP, s);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&tx, e0, e1));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(bcr_upd_kernel, dim3(bg_grid(2u * ns * O, nt)), dim3(BG_T), 0, 0, B.Li, B.C, B.XA, B.XAT, B.XB, B.XBT, N, O, MP, s);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&tu, e0, e1));
+        }
+        printf("dbg %2d: x %7.1f us (%5.1f TFLOP/s)   upd %7.1f us (%5.1f TFLOP/s)\n", dbg, tx * 1e3, fl_x / tx / 1e9, tu * 1e3, fl_u / tu / 1e9);
+    }
+    int z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(bcr_dbg), &z, sizeof(int)));
+    CK(hipFree(d));
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) { bench_products(); return 0; }
     srand(1234);
     test_potrf(16); test_potrf(48); test_potrf(128);
     test_gemm(16); test_gemm(80); test_gemm(128);
