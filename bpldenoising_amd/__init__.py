@@ -9,7 +9,9 @@ from .learning_function import (FwdGradientOp, L2CostFunction, TVDenoise, TVSolv
 from .sharding import ShardedLearningFunction, shard_range
 from .datasets import testdataset, load_filelist_dataset
 from . import trbox
+from . import experiments
+from .experiments import scalar_bilevel_tv_learn, patch_bilevel_tv_learn
 
 __all__ = ["FwdGradientOp", "L2CostFunction", "TVDenoise", "TVSolver", "denoise",
            "tv_op_learning_function", "generate_cost", "ShardedLearningFunction", "shard_range", "testdataset",
-           "load_filelist_dataset", "trbox"]
+           "load_filelist_dataset", "trbox", "experiments", "scalar_bilevel_tv_learn", "patch_bilevel_tv_learn"]

@@ -38,3 +38,39 @@ def test_patch_bilevel_cameraman(gpu_solver_cls, oracle):
     assert np.allclose(xg, xo, rtol=1e-6, atol=1e-12)
     assert [h["radius_value"] for h in hg] == [h["radius_value"] for h in ho]
     assert np.abs(ug - uo).max() < 1e-9
+
+
+def test_scalar_driver_end_to_end(gpu_solver_cls, oracle, tmp_path):
+    """`scalar_bilevel_tv_learn(dataset_name=..., num_samples=...)` with its default (HIP) learning function:
+    the same learned parameter and log as when the driver is run on the oracle, and the artefacts exist."""
+    import os
+    import bpldenoising_amd as B
+    kw = dict(npz=DATASETS_NPZ, dataset_name="faces_train_128_10", num_samples=3, maxiter=4, verbose_iter=0,
+              lf_kwargs=dict(maxiter=1500))
+    xg, ug, lg, wg = B.scalar_bilevel_tv_learn(out_root=str(tmp_path / "hip"), **kw)
+    kw["lf_kwargs"] = dict(maxiter=1500, nthreads=8)
+    xo, uo, lo, wo = B.scalar_bilevel_tv_learn(learning_function=oracle.tv_op_learning_function,
+                                               out_root=str(tmp_path / "cpu"), **kw)
+    assert xg == pytest.approx(xo, rel=1e-8) and np.abs(ug - uo).max() < 1e-9
+    assert [e["radius_value"] for e in lg] == [e["radius_value"] for e in lo]
+    assert os.path.exists(wg["perf"]) and os.path.exists(wg["quality"]) and len(wg["png"]) == 9
+    qg, qo = open(wg["quality"]).read().splitlines()[-1].split(), open(wo["quality"]).read().splitlines()[-1].split()
+    assert np.allclose([float(v) for v in qg], [float(v) for v in qo], rtol=1e-7)
+
+
+def test_cost_sweeps_and_validation(gpu_solver_cls, oracle, tmp_path):
+    """generate_scalar_tv_cost / generate_2d_tv_cost / validate_tv_parameter (src/BPLDenoising.jl:92-178,381-415)
+    through the batched sweep: every cost equals the one-by-one oracle value."""
+    import bpldenoising_amd.experiments as E
+    ub, f = T.load_dataset(DATASETS_NPZ, "circle_128_10")
+    rng1 = np.array([0.02, 0.1, 0.3])
+    c1 = E.generate_scalar_tv_cost("circle", rng1, npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=600)
+    ref = [oracle.cost(oracle.pdhg(f[:1], a, maxiter=600), ub[:1]) for a in rng1]
+    assert np.allclose(c1, ref, rtol=1e-12)
+    z = np.load(str(tmp_path / "circle_128_10" / "circle_128_10_cost.npz"))
+    assert np.array_equal(z["parameter_range"], rng1) and np.array_equal(z["costs"], c1)
+    c2 = E.generate_2d_tv_cost("circle", [0.05, 0.2], [0.1], npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=400)
+    ref2 = [oracle.cost(oracle.pdhg(f[:1], np.array([[a, 0.1]]), maxiter=400), ub[:1]) for a in (0.05, 0.2)]
+    assert c2.shape == (2, 1) and np.allclose(c2[:, 0], ref2, rtol=1e-12)
+    u, cost, w = E.validate_tv_parameter(0.1, dataset_name="circle", npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=500)
+    assert np.array_equal(u, oracle.pdhg(f, 0.1, maxiter=500)) and np.isclose(cost, oracle.cost(u, ub), rtol=1e-13)
