@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void bcr_init_kernel(const double* __restrict_
 // Cholesky factor of the 16x16 tile T (LDS, leading dimension ld) and its inverse, by one wave:
 // lane r holds row r, pivots and multipliers travel by readlane.  On exit the tile holds W = L^-1
 // (lower triangular, explicit zeros above).  Returns true on a non-positive pivot.
-__device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, int lane) {
+__device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, int lane, double* __restrict__ Lg = nullptr,
+                                              int ldg = 0) {
     const int lr = lane & 15;
     double m[16], di[16], x[16];
     bool bad = false;
@@ -115,6 +116,10 @@ __device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, in
     if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) T[lane + ld * c] = m[c];
+        if (Lg) {   // the Cholesky tile itself (lower), for callers that keep L (banded factorisation)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lg[lane + (size_t)ldg * c] = (c <= lane) ? m[c] : 0.0;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -135,25 +140,16 @@ __device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, in
     return bad;
 }
 
-// Cholesky factor of D_j and its inverse, in LDS.  grid (nelim, O) (or (1, O) with s = 0 for the
-// last block 0), block BCR_PT; dynamic LDS (MP+1)*MP doubles.  On exit D_j holds L^-1 (lower
-// triangular, zeros above) and DT_j its transpose.
+// Cholesky factor and its inverse of the symmetric MP x MP matrix held in LDS (S[r + (MP+1) c], both
+// triangles), by the BCR_PT threads of the workgroup.  On exit the lower tiles of S hold L (strictly
+// below the diagonal tiles) and the diagonal + upper tiles hold W = L^-1: W(r, c), r >= c, at
+// S[(16*(c>>4) + (r&15)) + ld*(16*(r>>4) + (c&15))].  Lg (nullable, leading dimension ldg): receives the
+// diagonal tiles of L.  Returns true (in wave 0) on a non-positive pivot.
 constexpr int BCR_PT = 512;
-__global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ D, double* __restrict__ DT, int N,
-                                                           int MP, int s, int* __restrict__ fail) {
-    extern __shared__ double S[];
+__device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int MP, double* __restrict__ Lg = nullptr,
+                                                   int ldg = 0) {
     const int ld = MP + 1, P = MP >> 4;
-    const int img = blockIdx.y;
-    const int j = (s == 0) ? 0 : s + 2 * s * (int)blockIdx.x;
-    const size_t bo = ((size_t)img * N + j) * MP * MP;
-    double* Dj = D + bo;
-    double* DTj = DT + bo;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    for (int e = tid; e < MP * MP; e += BCR_PT) {
-        const int r = e % MP, c = e / MP;
-        S[r + ld * c] = Dj[e];
-    }
-    __syncthreads();
     bool bad = false;
     for (int p = 0; p < P; ++p) {
         // (1) left-looking update of block column p: tile (i, p) -= sum_{q<p} L_iq L_pq^T
@@ -176,7 +172,8 @@ __global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ 
             __syncthreads();
         }
         // (2) diagonal tile: Cholesky and inverse in wave-0 registers (lane r holds row r)
-        if (wave == 0) bad |= bcr_diag_tile(S + (16 * p) + ld * (16 * p), ld, lane);
+        if (wave == 0)
+            bad |= bcr_diag_tile(S + (16 * p) + ld * (16 * p), ld, lane, Lg ? Lg + 16 * p + (size_t)ldg * (16 * p) : nullptr, ldg);
         __syncthreads();
         // (3) rows below: L_ip = A_ip W_pp^T      (4) inverse row panel: W_pq = -W_pp sum_k L_pk W_kq
         //     W_kq (k >= q) is kept in the upper tile (q, k): element (r', c') at S[(16q+r') + ld(16k+c')]
@@ -215,6 +212,28 @@ __global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ 
         }
         __syncthreads();
     }
+    return bad;
+}
+
+// Cholesky factor of D_j and its inverse, in LDS.  grid (nelim, O) (or (1, O) with s = 0 for the
+// last block 0), block BCR_PT; dynamic LDS (MP+1)*MP doubles.  On exit D_j holds L^-1 (lower
+// triangular, zeros above) and DT_j its transpose.
+__global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ D, double* __restrict__ DT, int N,
+                                                           int MP, int s, int* __restrict__ fail) {
+    extern __shared__ double S[];
+    const int ld = MP + 1;
+    const int img = blockIdx.y;
+    const int j = (s == 0) ? 0 : s + 2 * s * (int)blockIdx.x;
+    const size_t bo = ((size_t)img * N + j) * MP * MP;
+    double* Dj = D + bo;
+    double* DTj = DT + bo;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        S[r + ld * c] = Dj[e];
+    }
+    __syncthreads();
+    const bool bad = bcr_potrf_lds_body(S, MP);
     if (bad && lane == 0 && fail[img] == 0) fail[img] = j + 1;
     for (int e = tid; e < MP * MP; e += BCR_PT) {
         const int r = e % MP, c = e / MP;

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "adjoint_kernels.hpp"
+#include "adjoint_bcr_kernels.hpp"
 
 namespace bpltv {
 
@@ -171,6 +172,187 @@ __global__ __launch_bounds__(256) void hb_update_kernel(double* __restrict__ ban
             const int d = r - j;
             if (r < n && j < n && d >= 0 && d <= bw && r <= k0 + HB_NB - 1 + bw) Bi[(size_t)j * W + d] -= acc[a][b];
         }
+}
+
+// ---- 128-column panels on the f64 MFMA (hb2_*) -------------------------------------------------------
+// The 32-column panel kernels above cost ~50 us per panel whatever the arithmetic (kernel boundaries +
+// a sequential 32x32 Cholesky + scalar updates): 1.6 us per column.  With 128-column panels the same
+// three steps are the dense kernels of the block cyclic reduction, addressed into the band (the lower
+// band is a column-major matrix with leading dimension W-1: A(r, c) = band[r + (W-1) c]):
+//   hb2_potrf_kernel   diagonal block: Cholesky + inverse in LDS (bcr_potrf_lds_body)
+//   hb2_trsm_kernel    P = A21 L11^-T for the bw rows below (MFMA tiles; side panel buffer P)
+//   hb2_update_kernel  A22 -= P P^T on the lower 64x64 tiles of the trailing bw x bw block (MFMA),
+//                      and L11, P copied into the band
+// Side buffers per image: Linv11 (128 x 128), L11 (128 x 128), P (bwp x 128, bwp = bw rounded up to 64).
+constexpr int HB2_NB = 128;
+
+// grid (O), block BCR_PT, dynamic LDS bcr_potrf_lds(HB2_NB)
+__global__ __launch_bounds__(BCR_PT) void hb2_potrf_kernel(const double* __restrict__ band, int M, int N, int k0,
+                                                           double* __restrict__ Linv, double* __restrict__ L11,
+                                                           int* __restrict__ fail) {
+    extern __shared__ double S[];
+    constexpr int MP = HB2_NB, ld = MP + 1;
+    const int W = M + 1, bw = M, n = M * N;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const double* Bi = band + (size_t)img * n * W + (size_t)k0 * W;   // A(k0+r, k0+c) = Bi[r + (W-1) c], r >= c
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        double v = (r == c) ? 1.0 : 0.0;   // identity padding past the end of the matrix
+        if (k0 + hi < n) v = (hi - lo <= bw) ? Bi[hi + (size_t)(W - 1) * lo] : 0.0;
+        S[r + ld * c] = v;
+    }
+    __syncthreads();
+    double* Lg = L11 + (size_t)img * MP * MP;
+    const bool bad = bcr_potrf_lds_body(S, MP, Lg, MP);
+    if (bad && lane == 0 && fail[img] == 0) fail[img] = k0 + 1;
+    double* Li = Linv + (size_t)img * MP * MP;
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        Li[e] = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
+        if ((r >> 4) > (c >> 4)) Lg[e] = S[r + ld * c];          // strictly lower tiles of L
+        else if ((r >> 4) < (c >> 4)) Lg[e] = 0.0;               // (diagonal tiles were written by bcr_diag_tile)
+    }
+}
+
+// 64 x 32 chunk of the band as an MFMA operand: rows R0 + (tid & 63), columns K0 + (tid >> 6) + 4 i.
+__device__ __forceinline__ void hb2_fetch_band(const double* __restrict__ Bi, int W, int bw, int n, int R0, int K0,
+                                               int tid, double (&v)[8]) {
+    const int R = R0 + (tid & 63), kq = K0 + (tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int K = kq + 4 * i;
+        v[i] = (R < n && K < n && R >= K && R - K <= bw) ? Bi[(size_t)K * W + (R - K)] : 0.0;
+    }
+}
+// same from a dense column-major array with leading dimension ld (rows < rmax, columns < kmax)
+__device__ __forceinline__ void hb2_fetch_dense(const double* __restrict__ base, int ld, int rmax, int kmax, int r0,
+                                                int k0, int tid, double (&v)[8]) {
+    const int r = r0 + (tid & 63), kq = k0 + (tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kq + 4 * i;
+        v[i] = (r < rmax && k < kmax) ? base[r + (size_t)ld * k] : 0.0;
+    }
+}
+// one staged chunk (both operands row-fast): 8 k-steps of 2x2 MFMA tiles per wave
+__device__ __forceinline__ void hb2_mma_chunk(const double* __restrict__ As, const double* __restrict__ Bs, BgAcc& acc) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
+#pragma unroll
+    for (int kk = 0; kk < BG_KC / 4; ++kk) {
+        const int ko = (4 * kk + lk) * BG_LD;
+        const double a0 = As[ko + wr + lr], a1 = As[ko + wr + 16 + lr];
+        const double b0 = Bs[ko + wc + lr], b1 = Bs[ko + wc + 16 + lr];
+        acc.c[0][0] = bcr_mfma(a0, b0, acc.c[0][0]);
+        acc.c[0][1] = bcr_mfma(a0, b1, acc.c[0][1]);
+        acc.c[1][0] = bcr_mfma(a1, b0, acc.c[1][0]);
+        acc.c[1][1] = bcr_mfma(a1, b1, acc.c[1][1]);
+    }
+}
+
+// P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2, O), block BG_T.
+__global__ __launch_bounds__(BG_T) void hb2_trsm_kernel(const double* __restrict__ band, int M, int N, int k0,
+                                                        const double* __restrict__ Linv, double* __restrict__ P,
+                                                        int bwp) {
+    __shared__ double lds[BG_LDS];
+    const int W = M + 1, bw = M, n = M * N;
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int rt = blockIdx.x >> 1, c0 = (blockIdx.x & 1) * 64;
+    const int R0 = k0 + HB2_NB + 64 * rt;
+    if (R0 >= n) return;
+    const double* Bi = band + (size_t)img * n * W;
+    const double* Li = Linv + (size_t)img * HB2_NB * HB2_NB;
+    double* As = lds;
+    double* Bs = lds + BG_KC * BG_LD;
+    BgAcc acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (c0 + 64) / BG_KC;   // Linv11(c, k) = 0 for k > c
+    double va[8], vb[8];
+    hb2_fetch_band(Bi, W, bw, n, R0, k0, tid, va);
+    hb2_fetch_dense(Li, HB2_NB, HB2_NB, HB2_NB, c0, 0, tid, vb);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        bg_stage<true>(As, tid, va);
+        bg_stage<true>(Bs, tid, vb);
+        __syncthreads();
+        if (ch + 1 < nchunk) {
+            hb2_fetch_band(Bi, W, bw, n, R0, k0 + (ch + 1) * BG_KC, tid, va);
+            hb2_fetch_dense(Li, HB2_NB, HB2_NB, HB2_NB, c0, (ch + 1) * BG_KC, tid, vb);
+        }
+        hb2_mma_chunk(As, Bs, acc);
+    }
+    bg_to_lds(acc, lds);
+    double* Pi = P + (size_t)img * bwp * HB2_NB;
+    const int l = tid & 63, hq = tid >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int o = hq + 4 * i;
+        Pi[(64 * rt + l) + (size_t)bwp * (c0 + o)] = lds[o * BG_LD + l];
+    }
+}
+
+// Trailing update A(R, C) -= sum_k P(R, k) P(C, k) on the lower 64x64 tiles (ta >= tb) of the bw x bw block
+// behind the panel; the diagonal tiles also copy their 64 rows of P (= L21) into the band and tile 0
+// copies L11.  grid (nt (nt+1) / 2, O), nt = ceil(bw/64); block BG_T.
+__global__ __launch_bounds__(BG_T) void hb2_update_kernel(double* __restrict__ band, int M, int N, int k0,
+                                                          const double* __restrict__ L11, const double* __restrict__ P,
+                                                          int bwp) {
+    __shared__ double lds[BG_LDS];
+    const int W = M + 1, bw = M, n = M * N;
+    const int img = blockIdx.y, tid = threadIdx.x;
+    double* Bi = band + (size_t)img * n * W;
+    const double* Pi = P + (size_t)img * bwp * HB2_NB;
+    int ta = 0, t = blockIdx.x;
+    while (t > ta) { t -= ta + 1; ++ta; }
+    const int tb = t;   // tb <= ta
+    if (blockIdx.x == 0) {   // L11 of this panel into the band
+        const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
+        for (int e = tid; e < HB2_NB * HB2_NB; e += BG_T) {
+            const int r = e % HB2_NB, c = e / HB2_NB;
+            if (r >= c && k0 + r < n && r - c <= bw) Bi[(size_t)(k0 + c) * W + (r - c)] = Lg[e];
+        }
+    }
+    const int base = k0 + HB2_NB;
+    if (base + 64 * tb >= n) return;
+    if (ta == tb) {          // rows [64 ta, 64 ta + 64) of L21 into the band
+        for (int e = tid; e < 64 * HB2_NB; e += BG_T) {
+            const int rr = 64 * ta + (e & 63), c = e >> 6;
+            const int R = base + rr, K = k0 + c;
+            if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = Pi[rr + (size_t)bwp * c];
+        }
+    }
+    if (base + 64 * ta >= n) return;
+    double* As = lds;
+    double* Bs = lds + BG_KC * BG_LD;
+    BgAcc acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    double va[8], vb[8];
+    hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, 0, tid, va);
+    hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * tb, 0, tid, vb);
+    constexpr int nchunk = HB2_NB / BG_KC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        bg_stage<true>(As, tid, va);
+        bg_stage<true>(Bs, tid, vb);
+        __syncthreads();
+        if (ch + 1 < nchunk) {
+            hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, (ch + 1) * BG_KC, tid, va);
+            hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * tb, (ch + 1) * BG_KC, tid, vb);
+        }
+        hb2_mma_chunk(As, Bs, acc);
+    }
+    bg_to_lds(acc, lds);
+    const int l = tid & 63, hq = tid >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int o = hq + 4 * i;
+        const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
+        if (R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw)
+            Bi[(size_t)Cc * W + (R - Cc)] -= lds[o * BG_LD + l];
+    }
 }
 
 // Substitutions with L in the band array.  A single workgroup streaming the 8.6 GB factor of a

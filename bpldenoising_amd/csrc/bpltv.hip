@@ -127,6 +127,7 @@ struct bpltv_handle {
     bool adj_twisted = false;
     bool adj_hbm = false;  // M too wide for the LDS window: band factored in place in HBM
     double *d_band = nullptr, *d_l11 = nullptr;
+    double* d_hb2 = nullptr;   // 128-column panels: Linv11 | L11 | P per image
     double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
     double* d_resn = nullptr;
     int* d_fail = nullptr;
@@ -579,6 +580,10 @@ int band_alloc(bpltv_t* h) {
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
         HIPCHK(h, hipMalloc((void**)&h->d_band, need));
         HIPCHK(h, hipMalloc((void**)&h->d_l11, (size_t)h->O * HB_NB * HB_NB * sizeof(double)));
+        const size_t bwp = (size_t)(h->M + 63) / 64 * 64;
+        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * (2 * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(HB2_NB)));
     }
     if (!h->adj_hbm) HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
     if (h->adj_hbm) {
@@ -625,12 +630,13 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                       double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
-    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction
+    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction, 3 = banded Cholesky with the
+    // 32-column scalar panels of the HBM path (A/B measurements)
     const int method = p.reserved[4];
     if (method == 2 && !bcr_applicable(h))
         return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
                        h->M, h->N);
-    bool use_bcr = bcr_applicable(h) && method != 1;
+    bool use_bcr = bcr_applicable(h) && method != 1 && method != 3;
     if (use_bcr) {
         rc = bcr_alloc(h);
         if (rc == BPLTV_E_NOMEM && method == 0) use_bcr = false;  // the band needs 7x less memory
@@ -673,10 +679,24 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         const int n = (int)h->npx;
         const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2;
         const unsigned prow = (unsigned)((M + HB_NB + HB_ROWS - 1) / HB_ROWS);
-        for (int k0 = 0; k0 < n; k0 += HB_NB) {
-            hipLaunchKernelGGL(hb_panel_kernel, dim3(prow, O), dim3(HB_ROWS), 0, h->stream, h->d_band, M, N, k0, h->d_l11,
-                               h->d_fail);
-            hipLaunchKernelGGL(hb_update_kernel, dim3(ntile, O), dim3(256), 0, h->stream, h->d_band, M, N, k0, h->d_l11);
+        if (method == 3) {   // 32-column panels with scalar updates (kept for A/B measurements)
+            for (int k0 = 0; k0 < n; k0 += HB_NB) {
+                hipLaunchKernelGGL(hb_panel_kernel, dim3(prow, O), dim3(HB_ROWS), 0, h->stream, h->d_band, M, N, k0, h->d_l11,
+                                   h->d_fail);
+                hipLaunchKernelGGL(hb_update_kernel, dim3(ntile, O), dim3(256), 0, h->stream, h->d_band, M, N, k0, h->d_l11);
+            }
+        } else {             // 128-column panels on the f64 MFMA
+            const int bwp = nt * 64;
+            double* Linv = h->d_hb2;
+            double* L11 = Linv + (size_t)O * HB2_NB * HB2_NB;
+            double* P = L11 + (size_t)O * HB2_NB * HB2_NB;
+            for (int k0 = 0; k0 < n; k0 += HB2_NB) {
+                hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
+                                   Linv, L11, h->d_fail);
+                if (k0 + HB2_NB < n)
+                    hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, Linv, P, bwp);
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11, P, bwp);
+            }
         }
         HIPCHK(h, hipGetLastError());
     }
@@ -924,7 +944,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_bcr, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_bcr, h->d_hb2, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)
