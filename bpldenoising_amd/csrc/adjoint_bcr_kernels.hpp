@@ -228,6 +228,7 @@ __global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ 
     double* Dj = D + bo;
     double* DTj = DT + bo;
     const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll 8
     for (int e = tid; e < MP * MP; e += BCR_PT) {
         const int r = e % MP, c = e / MP;
         S[r + ld * c] = Dj[e];

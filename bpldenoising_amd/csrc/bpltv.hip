@@ -87,6 +87,8 @@ struct bpltv_handle {
     int M = 0, N = 0, O = 0, device = 0, ncu = 0;
     size_t npx = 0, tot = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // wide-image adjoint: trailing update beside the next panel's Cholesky
+    hipEvent_t ev_hb[2] = {nullptr, nullptr};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_data = false;
     // dataset + state
@@ -126,7 +128,7 @@ struct bpltv_handle {
     double *d_L1 = nullptr, *d_dump = nullptr, *d_Lm = nullptr, *d_spill = nullptr;  // twisted factorisation
     bool adj_twisted = false;
     bool adj_hbm = false;  // M too wide for the LDS window: band factored in place in HBM
-    double *d_band = nullptr, *d_l11 = nullptr;
+    double* d_band = nullptr;
     double* d_hb2 = nullptr;   // 128-column panels: Linv11 | L11 | P per image
     double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
     double* d_resn = nullptr;
@@ -574,24 +576,22 @@ int band_alloc(bpltv_t* h) {
     if (h->adj_hbm) {
         size_t freeb = 0, totalb = 0;
         (void)hipMemGetInfo(&freeb, &totalb);
-        const size_t need = tot * W * sizeof(double);
+        const size_t np_ = (h->npx + HB2_NB - 1) / HB2_NB;
+        const size_t need = (tot * W + (size_t)h->O * 2 * np_ * HB2_NB * HB2_NB) * sizeof(double);
         if (need + (2ull << 30) > freeb)
-            return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band of %d images of %dx%d needs %.1f GB of HBM (%.1f GB free)",
+            return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free)",
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
-        HIPCHK(h, hipMalloc((void**)&h->d_band, need));
-        HIPCHK(h, hipMalloc((void**)&h->d_l11, (size_t)h->O * HB_NB * HB_NB * sizeof(double)));
-        const size_t bwp = (size_t)(h->M + 63) / 64 * 64;
-        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * (2 * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_band, tot * W * sizeof(double)));
+        // 128-column panels: L11^-1 and L11^-T of every panel (for the substitutions) | L11 | P per image
+        const size_t bwp = (size_t)(h->M + 63) / 64 * 64, npanel = (h->npx + HB2_NB - 1) / HB2_NB;
+        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * ((2 * npanel + 1) * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(HB2_NB)));
-    }
-    if (!h->adj_hbm) HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
-    if (h->adj_hbm) {
-        const size_t nblk = (h->npx + SB - 1) / SB;
-        HIPCHK(h, hipMalloc((void**)&h->d_invF, (size_t)h->O * nblk * SB * SB * sizeof(double)));
-        HIPCHK(h, hipMalloc((void**)&h->d_invB, (size_t)h->O * nblk * SB * SB * sizeof(double)));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        for (auto& e : h->ev_hb) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (!h->adj_hbm) {
+        HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
         const size_t nblk = (h->npx + SB - 1) / SB;
         HIPCHK(h, hipMalloc((void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
         HIPCHK(h, hipMalloc((void**)&h->d_invB, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
@@ -630,13 +630,12 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                       double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
-    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction, 3 = banded Cholesky with the
-    // 32-column scalar panels of the HBM path (A/B measurements)
+    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction
     const int method = p.reserved[4];
     if (method == 2 && !bcr_applicable(h))
         return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
                        h->M, h->N);
-    bool use_bcr = bcr_applicable(h) && method != 1 && method != 3;
+    bool use_bcr = bcr_applicable(h) && method != 1;
     if (use_bcr) {
         rc = bcr_alloc(h);
         if (rc == BPLTV_E_NOMEM && method == 0) use_bcr = false;  // the band needs 7x less memory
@@ -671,33 +670,42 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         bcr_factor_band4_launch(h->stream, bcr, h->d_band4, M, N, O, MP, h->d_fail);
         HIPCHK(h, hipGetLastError());
     }
+    const int hb_np = (int)((h->npx + HB2_NB - 1) / HB2_NB);
+    double* hb_Linv = h->d_hb2;
+    double* hb_LinvT = hb_Linv ? hb_Linv + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
+    double* hb_L11 = hb_Linv ? hb_LinvT + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
+    double* hb_P = hb_Linv ? hb_L11 + (size_t)O * HB2_NB * HB2_NB : nullptr;
     if (!use_bcr && h->adj_hbm) {
         const size_t W = (size_t)M + 1;
         const size_t nel = h->npx * W;  // per image
         const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
         hipLaunchKernelGGL(hb_init_kernel, dim3(ib_blocks, O), dim3(256), 0, h->stream, h->d_band4, M, N, O, h->d_band);
         const int n = (int)h->npx;
-        const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2;
-        const unsigned prow = (unsigned)((M + HB_NB + HB_ROWS - 1) / HB_ROWS);
-        if (method == 3) {   // 32-column panels with scalar updates (kept for A/B measurements)
-            for (int k0 = 0; k0 < n; k0 += HB_NB) {
-                hipLaunchKernelGGL(hb_panel_kernel, dim3(prow, O), dim3(HB_ROWS), 0, h->stream, h->d_band, M, N, k0, h->d_l11,
-                                   h->d_fail);
-                hipLaunchKernelGGL(hb_update_kernel, dim3(ntile, O), dim3(256), 0, h->stream, h->d_band, M, N, k0, h->d_l11);
+        const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
+        bool rest_pending = false;
+        for (int k0 = 0; k0 < n; k0 += HB2_NB) {   // 128-column panels on the f64 MFMA
+            hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
+                               hb_np, hb_Linv, hb_LinvT, hb_L11, h->d_fail);
+            if (rest_pending) {   // the previous panel's trailing update must be complete from here on
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
+                rest_pending = false;
             }
-        } else {             // 128-column panels on the f64 MFMA
-            const int bwp = nt * 64;
-            double* Linv = h->d_hb2;
-            double* L11 = Linv + (size_t)O * HB2_NB * HB2_NB;
-            double* P = L11 + (size_t)O * HB2_NB * HB2_NB;
-            for (int k0 = 0; k0 < n; k0 += HB2_NB) {
-                hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
-                                   Linv, L11, h->d_fail);
-                if (k0 + HB2_NB < n)
-                    hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, Linv, P, bwp);
-                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11, P, bwp);
+            if (k0 + HB2_NB < n)
+                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb_np, hb_Linv,
+                                   hb_P, bwp);
+            // look-ahead: the three tiles of the next diagonal block first; the rest of the trailing update
+            // runs on a second stream beside the next panel's (latency-bound, O-workgroup) Cholesky
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb_L11, hb_P, bwp, 0);
+            if (ntile > 3) {
+                HIPCHK(h, hipEventRecord(h->ev_hb[0], h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_hb[0], 0));
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, hb_L11,
+                                   hb_P, bwp, 3);
+                HIPCHK(h, hipEventRecord(h->ev_hb[1], h->stream2));
+                rest_pending = true;
             }
         }
+        if (rest_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
         HIPCHK(h, hipGetLastError());
     }
     const int tw = (!use_bcr && h->adj_twisted) ? 1 : 0;
@@ -721,8 +729,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     if (use_bcr) {
         // the inverses of the diagonal factors come out of bcr_potrf_kernel
     } else if (h->adj_hbm) {
-        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_band, M, N, (int)h->npx,
-                           h->d_invF, h->d_invB);
+        // the inverted diagonal blocks come out of hb2_potrf_kernel
     } else if (tw) {
         hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
                            h->d_Lm, h->d_fail);
@@ -738,14 +745,14 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         if (use_bcr) {
             bcr_solve_launch(h->stream, bcr, M, N, O, MP, vec, accv, h->d_band4);
         } else if (h->adj_hbm) {
-            // one launch per 64-column block; d_gpix is free during the solves and holds y
+            // one launch per 128-column block; d_gpix is free during the solves and holds y
             const int n = (int)h->npx;
-            const unsigned chunks = 1 + (unsigned)((M + SB - 1) / SB);
-            for (int k0 = 0; k0 < n; k0 += SB)
-                hipLaunchKernelGGL(hb_fwd_block_kernel, dim3(chunks, O), dim3(64), 0, h->stream, h->d_band, h->d_invF, M, N, k0,
+            const unsigned chunks = 1 + (unsigned)((M + HB2_NB - 1) / HB2_NB);
+            for (int k0 = 0; k0 < n; k0 += HB2_NB)
+                hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb_Linv, M, N, k0, hb_np,
                                    vec, h->d_gpix);
-            for (int k0 = ((n - 1) / SB) * SB; k0 >= 0; k0 -= SB)
-                hipLaunchKernelGGL(hb_bwd_block_kernel, dim3(chunks, O), dim3(64), 0, h->stream, h->d_band, h->d_invB, M, N, k0,
+            for (int k0 = ((n - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
+                hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb_LinvT, M, N, k0, hb_np,
                                    h->d_gpix, vec, accv);
         } else if (tw) {
             hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
@@ -944,7 +951,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_bcr, h->d_hb2, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_l11, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_bcr, h->d_hb2, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)
@@ -955,6 +962,9 @@ int bpltv_destroy(bpltv_t* h) {
     if (h->d_sweep_cost) (void)hipFree(h->d_sweep_cost);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev_hb)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return BPLTV_OK;

@@ -110,7 +110,7 @@ class TVSolver:
         if dbg is not None:
             p.reserved[3] = int(dbg)       # timing experiments only (wrong results), see PdhgArgs::dbg
         if adjm is not None:
-            p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2, "band-scalar-panels": 3}.get(adjm, adjm)  # adjoint factorisation
+            p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2}.get(adjm, adjm)  # adjoint factorisation
         return p
 
     def _batch(self, a, what):
