@@ -176,8 +176,12 @@ __global__ __launch_bounds__(BG_T) void hb2_update_kernel(double* __restrict__ b
     int ta = 0, t = (int)blockIdx.x + tile0;
     while (t > ta) { t -= ta + 1; ++ta; }
     const int tb = t;   // tb <= ta
-    if (blockIdx.x + tile0 == 0) {   // L11 of this panel into the band
-        // explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory latency per iteration
+    const int base = k0 + HB2_NB;
+    // Copies of the finished panel into the band (only the substitutions read them): done by the
+    // workgroups of the second launch (tile0 = 3), off the critical path of the next panel's Cholesky.
+    // Explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory latency per iteration.
+    const int bx = (int)blockIdx.x;
+    if (tile0 != 0 && bx == 0) {           // L11
         const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
         for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
             double v[16];
@@ -190,24 +194,29 @@ __global__ __launch_bounds__(BG_T) void hb2_update_kernel(double* __restrict__ b
             }
         }
     }
-    const int base = k0 + HB2_NB;
-    if (base + 64 * tb >= n) return;
-    if (ta == tb) {          // rows [64 ta, 64 ta + 64) of L21 into the band
+    // rows [64 tc, 64 tc + 64) of L21: the diagonal tile tc >= 2 copies its own rows, workgroup 1 of the
+    // second launch those of the row tiles 0 and 1 (whose diagonal tiles belong to the first launch)
+    int tc0 = 0, tc1 = -1;
+    if (tile0 != 0 && bx == 1) { tc0 = 0; tc1 = 1; }
+    else if (tile0 != 0 && ta == tb) { tc0 = ta; tc1 = ta; }
+    for (int tc = tc0; tc <= tc1; ++tc) {
+        if (base + 64 * tc >= n) break;
         for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
             double v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int e = e0 + i * BG_T;
-                v[i] = Pi[64 * ta + (e & 63) + (size_t)bwp * (e >> 6)];
+                v[i] = Pi[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int e = e0 + i * BG_T, rr = 64 * ta + (e & 63), c = e >> 6;
+                const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
                 const int R = base + rr, K = k0 + c;
                 if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
             }
         }
     }
+    if (base + 64 * tb >= n) return;
     if (base + 64 * ta >= n) return;
     double* As = lds;
     double* Bs = lds + BG_KC * BG_LD;

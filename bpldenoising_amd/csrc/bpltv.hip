@@ -582,9 +582,10 @@ int band_alloc(bpltv_t* h) {
             return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free)",
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
         HIPCHK(h, hipMalloc((void**)&h->d_band, tot * W * sizeof(double)));
-        // 128-column panels: L11^-1 and L11^-T of every panel (for the substitutions) | L11 | P per image
+        // 128-column panels: L11^-1 and L11^-T of every panel (for the substitutions) | L11 (two buffers: the
+        // copy into the band runs beside the next panel's Cholesky) | P per image
         const size_t bwp = (size_t)(h->M + 63) / 64 * 64, npanel = (h->npx + HB2_NB - 1) / HB2_NB;
-        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * ((2 * npanel + 1) * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
+        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * ((2 * npanel + 2) * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(HB2_NB)));
         HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -674,7 +675,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     double* hb_Linv = h->d_hb2;
     double* hb_LinvT = hb_Linv ? hb_Linv + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
     double* hb_L11 = hb_Linv ? hb_LinvT + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
-    double* hb_P = hb_Linv ? hb_L11 + (size_t)O * HB2_NB * HB2_NB : nullptr;
+    double* hb_P = hb_Linv ? hb_L11 + 2 * (size_t)O * HB2_NB * HB2_NB : nullptr;
     if (!use_bcr && h->adj_hbm) {
         const size_t W = (size_t)M + 1;
         const size_t nel = h->npx * W;  // per image
@@ -684,8 +685,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
         bool rest_pending = false;
         for (int k0 = 0; k0 < n; k0 += HB2_NB) {   // 128-column panels on the f64 MFMA
+            double* L11p = hb_L11 + (size_t)((k0 / HB2_NB) & 1) * O * HB2_NB * HB2_NB;
             hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
-                               hb_np, hb_Linv, hb_LinvT, hb_L11, h->d_fail);
+                               hb_np, hb_Linv, hb_LinvT, L11p, h->d_fail);
             if (rest_pending) {   // the previous panel's trailing update must be complete from here on
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
                 rest_pending = false;
@@ -695,11 +697,11 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
                                    hb_P, bwp);
             // look-ahead: the three tiles of the next diagonal block first; the rest of the trailing update
             // runs on a second stream beside the next panel's (latency-bound, O-workgroup) Cholesky
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb_L11, hb_P, bwp, 0);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11p, hb_P, bwp, 0);
             if (ntile > 3) {
                 HIPCHK(h, hipEventRecord(h->ev_hb[0], h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_hb[0], 0));
-                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, hb_L11,
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, L11p,
                                    hb_P, bwp, 3);
                 HIPCHK(h, hipEventRecord(h->ev_hb[1], h->stream2));
                 rest_pending = true;
