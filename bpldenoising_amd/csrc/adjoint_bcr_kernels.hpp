@@ -449,17 +449,21 @@ __global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, d
         if (acc.c[0][0][0] == 12345.678) Out[0] = 0.0;
         return;
     }
-    bg_to_lds(acc, lds);
     const int tid = threadIdx.x;
     const int l = tid & 63, h = tid >> 6;
-#pragma unroll 4
+    // the 16 old values of the thread's entries are requested together, before the accumulators go
+    // through LDS (a read-modify-write loop would pay one memory latency per unrolled batch)
+    double old[16];
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int o = h + 4 * i;
-        if (r0 + l < MP && c0 + o < MP) {
-            const size_t e = (r0 + l) + (size_t)MP * (c0 + o);
-            const double v = lds[o * BG_LD + l];
-            Out[e] = (which == 0) ? Out[e] - v : -v;
-        }
+        old[i] = (which == 0 && r0 + l < MP && c0 + o < MP) ? Out[(r0 + l) + (size_t)MP * (c0 + o)] : 0.0;
+    }
+    bg_to_lds(acc, lds);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int o = h + 4 * i;
+        if (r0 + l < MP && c0 + o < MP) Out[(r0 + l) + (size_t)MP * (c0 + o)] = old[i] - lds[o * BG_LD + l];
     }
 }
 

@@ -238,14 +238,22 @@ __global__ __launch_bounds__(BG_T) void hb2_update_kernel(double* __restrict__ b
         }
         hb2_mma_chunk(As, Bs, acc);
     }
-    bg_to_lds(acc, lds);
     const int l = tid & 63, hq = tid >> 6;
-#pragma unroll 4
+    double old[16];   // requested together, before the accumulators go through LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int o = hq + 4 * i;
+        const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
+        const bool in = R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw;
+        old[i] = in ? Bi[(size_t)Cc * W + (R - Cc)] : 0.0;
+    }
+    bg_to_lds(acc, lds);
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int o = hq + 4 * i;
         const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
         if (R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw)
-            Bi[(size_t)Cc * W + (R - Cc)] -= lds[o * BG_LD + l];
+            Bi[(size_t)Cc * W + (R - Cc)] = old[i] - lds[o * BG_LD + l];
     }
 }
 
