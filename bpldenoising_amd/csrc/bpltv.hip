@@ -102,6 +102,7 @@ struct bpltv_handle {
     double* d_sweep_cost = nullptr;
     int result_buf = 0;  // which state set holds the last result
     bool has_result = false;
+    bool has_per_image = false;  // d_perimg (cost) and d_red (gradient partials) hold the last evaluate's rows
     double* d_alpha = nullptr;
     size_t alpha_cap = 0;
     int last_am = 1, last_an = 1;
@@ -380,6 +381,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
 }
 
 int compute_gap(bpltv_t* h, double* gap_host /*O or null*/, double* gap_max_host) {
+    h->has_per_image = false;   // d_perimg is about to hold the gaps
     const int nblk = 8;
     int rc = ensure(h, &h->d_red, &h->red_cap, (size_t)h->O * nblk * 4);
     if (rc) return rc;
@@ -399,6 +401,7 @@ int compute_gap(bpltv_t* h, double* gap_host /*O or null*/, double* gap_max_host
 }
 
 int run_pdhg(bpltv_t* h, const bpltv_params& p) {
+    h->has_per_image = false;
     if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
     if (p.maxiter < 0) return set_err(h, BPLTV_E_ARG, "maxiter < 0");
     Plan pl;
@@ -868,6 +871,7 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[4], h->ev[5]));
     h->st.cost_ms = ms;
     h->st.total_ms = wt.ms();
+    h->has_per_image = !(am == h->M && an == h->N && !(h->M == 1 && h->N == 1));
     return BPLTV_OK;
 }
 
@@ -1101,6 +1105,7 @@ int bpltv_grad_fwd_adjoint(bpltv_t* h, const double* y1, const double* y2, doubl
 
 int bpltv_gradient(bpltv_t* h, const double* u, const double* ubar, const double* alpha, int am, int an, int reg,
                    const bpltv_params* pp, double* grad_out) {
+    if (h) h->has_per_image = false;
     if (!h) return BPLTV_E_ARG;
     if (!u || !ubar || !grad_out) return set_err(h, BPLTV_E_ARG, "gradient: null pointer");
     WallTimer wt;
@@ -1185,6 +1190,22 @@ int bpltv_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const b
         cost_out[k] = sacc;
     }
     h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_per_image(bpltv_t* h, double* out) {
+    if (!h || !out) return BPLTV_E_ARG;
+    if (!h->has_per_image)
+        return set_err(h, BPLTV_E_UNSUPPORTED, "per-image pieces exist after evaluate with a scalar or patch parameter only");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int O = h->O, P = h->last_am * h->last_an;
+    std::vector<double> cost(O), g((size_t)P * O);
+    HIPCHK(h, hipMemcpy(cost.data(), h->d_perimg, sizeof(double) * O, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(g.data(), h->d_red, sizeof(double) * P * O, hipMemcpyDeviceToHost));   // [patch][image]
+    for (int k = 0; k < O; ++k) {
+        out[(size_t)k * (1 + P)] = cost[k];
+        for (int q = 0; q < P; ++q) out[(size_t)k * (1 + P) + 1 + q] = g[(size_t)q * O + k];
+    }
     return BPLTV_OK;
 }
 

@@ -141,6 +141,7 @@ class TVSolver:
 
     def evaluate(self, x, delta, fetch_u=True, **kw):
         a, am, an, scalar = _alpha_arg(x)
+        self._last_npar = am * an
         p = self.params(**kw)
         u = np.empty((self.O, self.N, self.M)) if fetch_u else None
         cost = C.c_double(0.0)
@@ -153,6 +154,7 @@ class TVSolver:
     def evaluate_partial(self, x, delta, fetch_u=True, **kw):
         """[cost, grad...] of this handle's images only (to be all-reduced across shards)."""
         a, am, an, _ = _alpha_arg(x)
+        self._last_npar = am * an
         p = self.params(**kw)
         u = np.empty((self.O, self.N, self.M)) if fetch_u else None
         part = np.empty(1 + am * an)
@@ -163,6 +165,7 @@ class TVSolver:
     def evaluate_device(self, x, delta, partial_ptr, **kw):
         """Partial vector written to device memory at `partial_ptr` (1 + am*an doubles)."""
         a, am, an, _ = _alpha_arg(x)
+        self._last_npar = am * an
         p = self.params(**kw)
         self._check(self._lib.bpltv_evaluate_device(self._h, _ptr(a), am, an, float(delta), C.byref(p),
                                                     C.c_void_p(partial_ptr)))
@@ -194,6 +197,13 @@ class TVSolver:
         self._check(self._lib.bpltv_sweep(self._h, _ptr(a), K, am, an, C.byref(p), _ptr(costs),
                                           _ptr(u) if fetch_u else None))
         return (costs, u) if fetch_u else costs
+
+    def per_image(self):
+        """(O, 1 + am*an) rows [cost_k, grad_k...] of the last evaluate (scalar / patch parameter): the totals
+        are these rows added in image order."""
+        out = np.empty((self.O, 1 + self._last_npar))
+        self._check(self._lib.bpltv_per_image(self._h, _ptr(out)))
+        return out
 
     def u_device_ptr(self):
         p = C.c_void_p()

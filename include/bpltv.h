@@ -23,7 +23,7 @@
  *     One call in flight per handle; calls block until the device work is complete.
  *   - One handle drives one GPU.  Multi-GPU = one process (or handle) per GPU, images sharded by
  *     the host layer, one all-reduce of the [cost, grad...] partial vector (bpltv_evaluate_partial /
- *     bpltv_evaluate_device); see INTEGRATION.md.
+ *     bpltv_evaluate_device; bpltv_per_image for sharding-independent sums); see INTEGRATION.md.
  */
 #ifndef BPLTV_H
 #define BPLTV_H
@@ -128,6 +128,12 @@ int bpltv_evaluate_partial(bpltv_t *h, const double *alpha, int am, int an, doub
  * ready for an RCCL all-reduce without a host round trip. */
 int bpltv_evaluate_device(bpltv_t *h, const double *alpha, int am, int an, double delta,
                           const bpltv_params *p, double *d_partial);
+
+/* Per-image pieces of the last evaluate (scalar or patch parameter; BPLTV_E_UNSUPPORTED for a pixel map):
+ * out (host, O*(1 + am*an) doubles), image k at out + k*(1 + am*an): [cost_k, grad_k...].  The totals of
+ * evaluate are these rows added in image order, so a host that gathers the rows of all shards and adds
+ * them in global image order gets results that do not depend on how the images were sharded. */
+int bpltv_per_image(bpltv_t *h, double *out);
 
 /* Device pointer of the last primal result u (M*N*O doubles, valid until the next call). */
 int bpltv_u_device(bpltv_t *h, const double **d_u);

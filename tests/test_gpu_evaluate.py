@@ -295,7 +295,10 @@ def _gpu_rank_worker(rank, world, port, q):
     ub, f = sb(5, 64, 64, seed=28)
     fn = ShardedLearningFunction((ub, f))          # HIP solver per rank, all ranks on cuda:0
     u, cost, grad = fn(np.array([[0.08, 0.12], [0.1, 0.05]]), 0.1, maxiter=300)
-    q.put((rank, fn.lo, fn.hi, u, cost, np.asarray(grad)))
+    fd = ShardedLearningFunction((ub, f), solver_factory=lambda *a: fn.solver, deterministic=True)
+    fd.solver = fn.solver                          # same handle, rows added in global image order
+    _, cd, gd = fd(np.array([[0.08, 0.12], [0.1, 0.05]]), 0.1, maxiter=300, fetch_u=False)
+    q.put((rank, fn.lo, fn.hi, u, cost, np.asarray(grad), cd, np.asarray(gd)))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -318,10 +321,17 @@ def test_two_rank_sharded_evaluate_on_one_gpu(gpu_solver_cls, oracle):
     P = np.array([[0.08, 0.12], [0.1, 0.05]])
     u0 = oracle.pdhg(f, P, maxiter=300)
     c0, g0 = oracle.cost(u0, ub), oracle.gradient(P, u0, ub)
-    for rank, lo, hi, u, cost, grad in res:
+    s1 = gpu_solver_cls(64, 64, 5)                 # one handle over the whole batch
+    s1.set_data(ub, f)
+    _, c1, g1 = s1.evaluate(P, 0.1, maxiter=300, fetch_u=False)
+    assert np.allclose(s1.per_image().sum(axis=0), np.concatenate([[c1], np.ravel(g1)]), rtol=1e-13)
+    s1.close()
+    for rank, lo, hi, u, cost, grad, cd, gd in res:
         assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
         assert np.array_equal(u, u0[lo:hi])
         assert np.isclose(cost, c0, rtol=1e-13) and np.allclose(grad, g0, rtol=1e-6)
+        # deterministic mode: bitwise what a single handle over all five images returns
+        assert cd == c1 and np.array_equal(gd, g1)
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 17])

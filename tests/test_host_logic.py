@@ -84,7 +84,14 @@ class FakeSolver:
     def evaluate_partial(self, x, delta, fetch_u=True, **kw):
         from oracle import c_oracle as co
         u, c, g = co.tv_op_learning_function(x, (self.ubar, self.f), delta, maxiter=kw.get("maxiter", 5000))
+        self._rows = []
+        for k in range(self.O):   # per-image rows, as bpltv_per_image returns them
+            _, ck, gk = co.tv_op_learning_function(x, (self.ubar[k:k + 1], self.f[k:k + 1]), delta, maxiter=kw.get("maxiter", 5000))
+            self._rows.append(np.concatenate([[ck], np.atleast_1d(np.asarray(gk)).reshape(-1)]))
         return (u if fetch_u else None), np.concatenate([[c], np.atleast_1d(np.asarray(g)).reshape(-1)])
+
+    def per_image(self):
+        return np.array(self._rows)
 
 
 def test_sharded_learning_function_single_process(oracle):
