@@ -629,26 +629,158 @@ int band_alloc(bpltv_t* h) {
     return BPLTV_OK;
 }
 
+// ---- the three factorisations of the reduced adjoint system ----------------------
+enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3 };   // also bpltv_stats_t::reserved[0]
+
+// Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
+// reduction) and make sure its workspace exists.
+int adj_choose(bpltv_t* h, const bpltv_params& p, AdjMethod* out) {
+    const int want = p.reserved[4];
+    if (want == 2 && !bcr_applicable(h))
+        return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
+                       h->M, h->N);
+    if (bcr_applicable(h) && want != 1) {
+        const int rc = bcr_alloc(h);
+        if (rc == BPLTV_OK) { *out = ADJ_BCR; return BPLTV_OK; }
+        if (!(rc == BPLTV_E_NOMEM && want == 0)) return rc;   // automatic choice: the band needs 7x less memory
+    }
+    const int rc = band_alloc(h);
+    if (rc) return rc;
+    *out = h->adj_hbm ? ADJ_BAND_HBM : ADJ_BAND_LDS;
+    return BPLTV_OK;
+}
+
+// Side buffers of the HBM band path, carved out of d_hb2.
+struct HbBuffers {
+    int npanel;
+    double *Linv, *LinvT, *L11, *P;
+    explicit HbBuffers(const bpltv_t* h) {
+        npanel = (int)((h->npx + HB2_NB - 1) / HB2_NB);
+        const size_t blk = (size_t)h->O * HB2_NB * HB2_NB;
+        Linv = h->d_hb2;
+        LinvT = Linv ? Linv + blk * npanel : nullptr;
+        L11 = Linv ? LinvT + blk * npanel : nullptr;     // two buffers (panel parity)
+        P = Linv ? L11 + 2 * blk : nullptr;
+    }
+};
+
+// Banded Cholesky in HBM (M > 138): panels of 128 columns, see adjoint_hbm_kernels.hpp.
+int factor_band_hbm(bpltv_t* h) {
+    const int M = h->M, N = h->N, O = h->O, n = (int)h->npx;
+    const HbBuffers hb(h);
+    const size_t nel = h->npx * ((size_t)M + 1);  // per image
+    const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
+    hipLaunchKernelGGL(hb_init_kernel, dim3(ib_blocks, O), dim3(256), 0, h->stream, h->d_band4, M, N, O, h->d_band);
+    const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
+    bool rest_pending = false;
+    for (int k0 = 0; k0 < n; k0 += HB2_NB) {
+        double* L11p = hb.L11 + (size_t)((k0 / HB2_NB) & 1) * O * HB2_NB * HB2_NB;
+        hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
+                           hb.npanel, hb.Linv, hb.LinvT, L11p, h->d_fail);
+        if (rest_pending) {   // the previous panel's trailing update must be complete from here on
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
+            rest_pending = false;
+        }
+        if (k0 + HB2_NB < n)
+            hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb.npanel,
+                               hb.Linv, hb.P, bwp);
+        // look-ahead: the three tiles of the next diagonal block first; the rest of the trailing update
+        // runs on a second stream beside the next panel's (latency-bound, O-workgroup) Cholesky
+        hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11p, hb.P, bwp, 0);
+        if (ntile > 3) {
+            HIPCHK(h, hipEventRecord(h->ev_hb[0], h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_hb[0], 0));
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, L11p, hb.P,
+                               bwp, 3);
+            HIPCHK(h, hipEventRecord(h->ev_hb[1], h->stream2));
+            rest_pending = true;
+        }
+    }
+    if (rest_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
+    HIPCHK(h, hipGetLastError());
+    return BPLTV_OK;
+}
+
+// vec <- A^-1 vec, accv += solution: one launch per 128-column block and direction; d_gpix is free during
+// the solves and holds y.
+void solve_band_hbm(bpltv_t* h, double* vec, double* accv) {
+    const int M = h->M, N = h->N, O = h->O, n = (int)h->npx;
+    const HbBuffers hb(h);
+    const unsigned chunks = 1 + (unsigned)((M + HB2_NB - 1) / HB2_NB);
+    for (int k0 = 0; k0 < n; k0 += HB2_NB)
+        hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb.Linv, M, N, k0, hb.npanel,
+                           vec, h->d_gpix);
+    for (int k0 = ((n - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
+        hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb.LinvT, M, N, k0, hb.npanel,
+                           h->d_gpix, vec, accv);
+}
+
+// Banded Cholesky with the trailing window in LDS (M <= 138), twisted when the shape allows.
+struct LdsBandPlan {
+    int tw;
+    unsigned nblk;
+    AdjSplit sp;
+    size_t mid_lds;
+    double *invF1, *invB1;
+    explicit LdsBandPlan(const bpltv_t* h) {
+        tw = h->adj_twisted ? 1 : 0;
+        nblk = (unsigned)((h->npx + SB - 1) / SB);
+        sp = adj_split((int)h->npx, h->M);
+        mid_lds = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
+        invF1 = h->d_invF + (size_t)h->O * nblk * SB * SB;
+        invB1 = h->d_invB + (size_t)h->O * nblk * SB * SB;
+    }
+};
+
+void factor_band_lds(bpltv_t* h) {
+    const int M = h->M, N = h->N, O = h->O;
+    const LdsBandPlan pl(h);
+    const dim3 fgrid(O, pl.tw ? 2 : 1);
+    if (M == 128)  // compile-time instance: addressing folded
+        hipLaunchKernelGGL((adj_factor_kernel<8, 128>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, pl.tw, h->d_dump, h->d_fail);
+    else if (adj_factor_lds(M, 8) <= 160 * 1024)
+        hipLaunchKernelGGL((adj_factor_kernel<8, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, pl.tw, h->d_dump, h->d_fail);
+    else
+        hipLaunchKernelGGL((adj_factor_kernel<4, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 4), h->stream,
+                           h->d_band4, M, N, O, h->d_L, h->d_L1, pl.tw, h->d_dump, h->d_fail);
+    if (pl.tw) {
+        hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), pl.mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
+                           h->d_Lm, h->d_fail);
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(pl.nblk, O), dim3(64), 0, h->stream, h->d_L, M, N, pl.sp.m, h->d_invF,
+                           h->d_invB);
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(pl.nblk, O), dim3(64), 0, h->stream, h->d_L1, M, N, pl.sp.nbot, pl.invF1,
+                           pl.invB1);
+    } else {
+        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(pl.nblk, O), dim3(64), 0, h->stream, h->d_L, M, N, (int)h->npx,
+                           h->d_invF, h->d_invB);
+    }
+}
+
+void solve_band_lds(bpltv_t* h, double* vec, double* accv) {
+    const int M = h->M, N = h->N, O = h->O;
+    const LdsBandPlan pl(h);
+    if (pl.tw) {
+        hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
+                           h->d_invB, M, N, vec, accv, h->d_spill);
+        hipLaunchKernelGGL(adj_mid_solve_kernel, dim3(O), dim3(256), pl.mid_lds, h->stream, h->d_Lm, M, N, vec, accv,
+                           h->d_spill);
+        hipLaunchKernelGGL(adj_solve_tw_kernel<1>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
+                           h->d_invB, M, N, vec, accv, h->d_spill);
+    } else {
+        hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, h->d_invF, h->d_invB, M, N, vec, accv);
+    }
+}
+
 // Adjoint gradient of the images (d_u, d_ubar) on the device; result (am*an doubles) -> d_out.
 int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
                       double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
-    // reserved[4]: 0 = automatic, 1 = banded Cholesky, 2 = block cyclic reduction
-    const int method = p.reserved[4];
-    if (method == 2 && !bcr_applicable(h))
-        return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
-                       h->M, h->N);
-    bool use_bcr = bcr_applicable(h) && method != 1;
-    if (use_bcr) {
-        rc = bcr_alloc(h);
-        if (rc == BPLTV_E_NOMEM && method == 0) use_bcr = false;  // the band needs 7x less memory
-        else if (rc) return rc;
-    }
-    if (!use_bcr) {
-        rc = band_alloc(h);
-        if (rc) return rc;
-    }
+    AdjMethod method;
+    rc = adj_choose(h, p, &method);
+    if (rc) return rc;
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
     const size_t tot = h->tot;
     const int patch = !(am == 1 && an == 1);
@@ -663,114 +795,28 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     C.h1 = h->d_coef + 4 * tot; C.h2 = h->d_coef + 5 * tot; C.s = h->d_coef + 6 * tot; C.rhs = h->d_coef + 7 * tot;
     const int gpx = (int)((tot + 255) / 256);
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    // coefficients and the four diagonals of the matrix
     hipLaunchKernelGGL(adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N,
                        O, patch, reg, kact, C);
     hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
-    // ---- block cyclic reduction -------------------------------------------------------------
-    const int MP = h->bcr_MP;
-    const BcrArrays bcr = BcrArrays::carve(h->d_bcr, M, N, O, MP);
-    if (use_bcr) {
-        bcr_factor_band4_launch(h->stream, bcr, h->d_band4, M, N, O, MP, h->d_fail);
-        HIPCHK(h, hipGetLastError());
-    }
-    const int hb_np = (int)((h->npx + HB2_NB - 1) / HB2_NB);
-    double* hb_Linv = h->d_hb2;
-    double* hb_LinvT = hb_Linv ? hb_Linv + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
-    double* hb_L11 = hb_Linv ? hb_LinvT + (size_t)O * hb_np * HB2_NB * HB2_NB : nullptr;
-    double* hb_P = hb_Linv ? hb_L11 + 2 * (size_t)O * HB2_NB * HB2_NB : nullptr;
-    if (!use_bcr && h->adj_hbm) {
-        const size_t W = (size_t)M + 1;
-        const size_t nel = h->npx * W;  // per image
-        const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
-        hipLaunchKernelGGL(hb_init_kernel, dim3(ib_blocks, O), dim3(256), 0, h->stream, h->d_band4, M, N, O, h->d_band);
-        const int n = (int)h->npx;
-        const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
-        bool rest_pending = false;
-        for (int k0 = 0; k0 < n; k0 += HB2_NB) {   // 128-column panels on the f64 MFMA
-            double* L11p = hb_L11 + (size_t)((k0 / HB2_NB) & 1) * O * HB2_NB * HB2_NB;
-            hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
-                               hb_np, hb_Linv, hb_LinvT, L11p, h->d_fail);
-            if (rest_pending) {   // the previous panel's trailing update must be complete from here on
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
-                rest_pending = false;
-            }
-            if (k0 + HB2_NB < n)
-                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb_np, hb_Linv,
-                                   hb_P, bwp);
-            // look-ahead: the three tiles of the next diagonal block first; the rest of the trailing update
-            // runs on a second stream beside the next panel's (latency-bound, O-workgroup) Cholesky
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11p, hb_P, bwp, 0);
-            if (ntile > 3) {
-                HIPCHK(h, hipEventRecord(h->ev_hb[0], h->stream));
-                HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_hb[0], 0));
-                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, L11p,
-                                   hb_P, bwp, 3);
-                HIPCHK(h, hipEventRecord(h->ev_hb[1], h->stream2));
-                rest_pending = true;
-            }
-        }
-        if (rest_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
-        HIPCHK(h, hipGetLastError());
-    }
-    const int tw = (!use_bcr && h->adj_twisted) ? 1 : 0;
-    const dim3 fgrid(O, tw ? 2 : 1);
-    if (use_bcr || h->adj_hbm) {
-        // factor done above
-    } else if (M == 128)  // the size of every shipped dataset: addressing folded at compile time
-        hipLaunchKernelGGL((adj_factor_kernel<8, 128>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
-    else if (adj_factor_lds(M, 8) <= 160 * 1024)
-        hipLaunchKernelGGL((adj_factor_kernel<8, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 8), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
-    else
-        hipLaunchKernelGGL((adj_factor_kernel<4, 0>), fgrid, dim3(ADJ_FT), adj_factor_lds(M, 4), h->stream,
-                           h->d_band4, M, N, O, h->d_L, h->d_L1, tw, h->d_dump, h->d_fail);
-    const unsigned nblk_tot = (unsigned)((h->npx + SB - 1) / SB);
-    const AdjSplit sp = adj_split((int)h->npx, M);
-    const size_t mid_lds = sizeof(double) * ((size_t)sp.nm * (sp.nm + 1) + sp.nm);
-    double* invF1 = h->d_invF + (size_t)O * nblk_tot * SB * SB;
-    double* invB1 = h->d_invB + (size_t)O * nblk_tot * SB * SB;
-    if (use_bcr) {
-        // the inverses of the diagonal factors come out of bcr_potrf_kernel
-    } else if (h->adj_hbm) {
-        // the inverted diagonal blocks come out of hb2_potrf_kernel
-    } else if (tw) {
-        hipLaunchKernelGGL(adj_mid_factor_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_band4, h->d_dump, M, N, O,
-                           h->d_Lm, h->d_fail);
-        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L, M, N, sp.m, h->d_invF,
-                           h->d_invB);
-        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L1, M, N, sp.nbot, invF1,
-                           invB1);
+    // factorisation
+    const BcrArrays bcr = BcrArrays::carve(h->d_bcr, M, N, O, h->bcr_MP);
+    if (method == ADJ_BCR) {
+        bcr_factor_band4_launch(h->stream, bcr, h->d_band4, M, N, O, h->bcr_MP, h->d_fail);
+    } else if (method == ADJ_BAND_HBM) {
+        rc = factor_band_hbm(h);
+        if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(adj_invdiag_kernel, dim3(nblk_tot, O), dim3(64), 0, h->stream, h->d_L, M, N, (int)h->npx,
-                           h->d_invF, h->d_invB);
+        factor_band_lds(h);
     }
+    HIPCHK(h, hipGetLastError());
     auto solve = [&](double* vec, double* accv) {
-        if (use_bcr) {
-            bcr_solve_launch(h->stream, bcr, M, N, O, MP, vec, accv, h->d_band4);
-        } else if (h->adj_hbm) {
-            // one launch per 128-column block; d_gpix is free during the solves and holds y
-            const int n = (int)h->npx;
-            const unsigned chunks = 1 + (unsigned)((M + HB2_NB - 1) / HB2_NB);
-            for (int k0 = 0; k0 < n; k0 += HB2_NB)
-                hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb_Linv, M, N, k0, hb_np,
-                                   vec, h->d_gpix);
-            for (int k0 = ((n - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
-                hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb_LinvT, M, N, k0, hb_np,
-                                   h->d_gpix, vec, accv);
-        } else if (tw) {
-            hipLaunchKernelGGL(adj_solve_tw_kernel<0>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
-                               h->d_invB, M, N, vec, accv, h->d_spill);
-            hipLaunchKernelGGL(adj_mid_solve_kernel, dim3(O), dim3(256), mid_lds, h->stream, h->d_Lm, M, N, vec, accv,
-                               h->d_spill);
-            hipLaunchKernelGGL(adj_solve_tw_kernel<1>, dim3(O, 2), dim3(256), 0, h->stream, h->d_L, h->d_L1, h->d_invF,
-                               h->d_invB, M, N, vec, accv, h->d_spill);
-        } else {
-            hipLaunchKernelGGL(adj_solve_kernel, dim3(O), dim3(256), 0, h->stream, h->d_L, h->d_invF, h->d_invB, M, N, vec,
-                               accv);
-        }
+        if (method == ADJ_BCR) bcr_solve_launch(h->stream, bcr, M, N, O, h->bcr_MP, vec, accv, h->d_band4);
+        else if (method == ADJ_BAND_HBM) solve_band_hbm(h, vec, accv);
+        else solve_band_lds(h, vec, accv);
     };
+    // solve + iterative refinement against the matrix-free operator
     HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     solve(h->d_p, nullptr);
     for (int it = 0; it < nref; ++it) {
@@ -779,6 +825,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     }
     hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
     hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, (int)h->npx, h->d_resn);
+    // gradient per pixel, then per parameter
     hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
                        h->d_gpix);
     if (am == M && an == N && !(M == 1 && N == 1)) {  // pixelwise parameter map: plain sum over images
@@ -803,12 +850,12 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
-    h->st.reserved[0] = use_bcr ? 2 : (h->adj_hbm ? 3 : 1);
+    h->st.reserved[0] = (int)method;
     double worst = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
             return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at %s %d of image %d",
-                           use_bcr ? "block" : "column", fail[k] - 1, k);
+                           method == ADJ_BCR ? "block" : "column", fail[k] - 1, k);
         const double r = std::sqrt(resn[2 * k]) / (resn[2 * k + 1] > 0 ? std::sqrt(resn[2 * k + 1]) : 1.0);
         if (r > worst) worst = r;
     }
