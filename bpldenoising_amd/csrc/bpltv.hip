@@ -789,7 +789,10 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     double kact = 1.0 / (patch ? std::sqrt(eps) : eps);  // TVLearningFunctionVec.jl:128 / :245
     if (kact > kcap) kact = kcap;
     kact *= kappa_scale;
-    const int nref = p.refine < 0 ? 3 : p.refine;
+    // Refinement sweeps: every sweep gains ~2 digits with the 1e14 active-set weight of the scalar gradient and
+    // 4-5 digits with the 6.7e7 / 1e8 weights of the patch and regularised gradients, where the second sweep
+    // already reaches rounding level (tools/gpu_refine.py).
+    const int nref = p.refine < 0 ? ((patch || reg) ? 2 : 3) : p.refine;
     AdjCoef C;
     C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;
     C.h1 = h->d_coef + 4 * tot; C.h2 = h->d_coef + 5 * tot; C.s = h->d_coef + 6 * tot; C.rhs = h->d_coef + 7 * tot;

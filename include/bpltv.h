@@ -65,7 +65,8 @@ typedef struct bpltv_params {
                             0 = library default for the image size                                */
     int use_graph;       /* 1 (default): replay the launch sequence from a hipGraph               */
     double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
-    int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3)   */
+    int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3 for the
+                            scalar gradient, 2 for patch / pixel-map parameters and gradient_reg)  */
     int reserved[5];     /* tuning / measurement knobs, 0 = default:
                             [0] PDHG kernel variant (1-based index into the variant table of bpltv.hip)
                             [1] number of independent launch chains (image groups replayed concurrently)
