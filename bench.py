@@ -156,13 +156,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev_ms, ev_launches = 0.0, 0
+    ev_ms, ev_launches, ev_steps = 0.0, 0, []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         if solver is not None:
             st = solver.stats()
             ev_ms += st["pdhg_ms"]          # HIP events on the library's own stream
+            ev_steps.append(st["pdhg_ms"])
             ev_launches += st["launches"]
     fence()
     dt = time.perf_counter() - t0
@@ -219,6 +220,7 @@ def main():
                          "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
                          "bytes_per_px_iter": bytes_px},
             "pdhg_event_ms_per_step": ev_ms / args.steps,
+            "pdhg_event_ms_median": float(np.median(ev_steps)) if ev_steps else None,   # median of the repeats
         }
         if world == 1 and not args.evaluate and M * N * O_local <= 16 * 128 * 128:
             # outside the timed region: one full learning-function evaluation on the same resident batch
