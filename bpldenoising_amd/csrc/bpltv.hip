@@ -47,7 +47,7 @@ void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
-    VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread   (large images, deep blocking)
+    VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
     VAR(1, 1, 16, 16),  // 3: 16x16 region
     VAR(2, 2, 16, 16),  // 4: 32x32 region, 256 threads
     VAR(2, 1, 32, 32),  // 5: 64x32 region
@@ -58,7 +58,7 @@ const Variant kVariants[] = {
     VAR(1, 2, 32, 32),  // 10: 32x64 region
     VAR(1, 2, 40, 20),  // 11: 40x40 region, 800 threads, 2 px/thread (core 24 at T = 8: 5x5 tiles per 128^2 image)
     VAR(2, 2, 20, 20),  // 12: 40x40 region, 400 threads, 4 px/thread
-    VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread
+    VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread   (default for images larger than 256)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -241,7 +241,7 @@ struct Plan {
 int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     int v = p.reserved[0] - 1;  // explicit variant (1-based), 0 = auto
     const int M = h->M, N = h->N;
-    if (v < 0) v = (M > 256 || N > 256) ? 1 : 0;
+    if (v < 0) v = (M > 256 || N > 256) ? 12 : 0;   // large images: 48x48 regions (variant 13), see below
     if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
     const Variant& V = kVariants[v];
     int T = p.tile_iters;
@@ -261,7 +261,13 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
             if (cost < best) { best = cost; T = t; }
         }
     }
-    if (T <= 0) T = 8;  // 64x64-region variants: measured best on MI355X (profiles/)
+    if (T <= 0) {
+        // Large images (tools/gpu_cfg5b.py: 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
+        // of 3 px/thread beat the 64x64 / 4 px variant by 7-18 %; depth 8, or 6 once the grid is
+        // many times the chip (the smaller halo then saves more arithmetic than the extra launches cost).
+        T = 8;
+        if (v == 12 && (double)tile_count(M, V.RI, 8) * tile_count(N, V.RJ, 8) * h->cur_nimg > 8192.0) T = 6;
+    }
     // the halo must leave a core when the image is larger than the region
     auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
     int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
