@@ -243,24 +243,35 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     const int M = h->M, N = h->N;
     if (v < 0) v = (M > 256 || N > 256) ? 12 : 0;   // large images: 48x48 regions (variant 13), see below
     if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
-    const Variant& V = kVariants[v];
     int T = p.tile_iters;
+    const bool auto_variant = p.reserved[0] <= 0;
     if (T <= 0 && v == 0) {
-        // Fusion depth from a launch-cost model fitted on MI355X (tools/gpu_o1.py): a launch costs a
-        // fixed ~4.5 us plus T iterations of ~0.47 us while every CU holds at most one workgroup,
-        // ~0.94 us per round of two co-resident workgroups per CU beyond that.  Deeper fusion means
-        // fewer launches but smaller cores, i.e. more (redundant) tiles.  Results do not depend on T.
+        // Region and fusion depth from a launch-cost model fitted on MI355X (tools/gpu_o1.py, tools/gpu_v128.py):
+        // a launch costs a fixed ~4.5 us plus T iterations; an iteration of the 32x32 / 1 px kernel takes
+        // ~0.47 us while every CU holds at most one workgroup and ~0.94 us per round of two co-resident
+        // workgroups beyond that, one of the 48x48 / 3 px kernel 1.36 us resp. 2.1 us.  Deeper fusion means
+        // fewer launches but smaller cores, i.e. more (redundant) tiles; the larger region wastes fewer pixels on
+        // halos and wins once the batch no longer fits the chip with 32x32 regions (16 images of 128^2: -10 %,
+        // 32: -27 %).  Results do not depend on the choice.
+        struct Cand { int v; double one, two; };
+        const Cand cands[2] = {{0, 0.47, 0.94}, {12, 1.36, 2.1}};
         double best = 1e300;
         const int ncu = h->ncu > 0 ? h->ncu : 256;
-        for (int t = 2; t <= 12; ++t) {
-            const int a = tile_count(M, V.RI, t), b = tile_count(N, V.RJ, t);
-            if (a < 1 || b < 1) continue;
-            const double tiles = (double)a * b * h->cur_nimg;
-            const double per_iter = (tiles <= ncu) ? 0.47 : 0.94 * std::ceil(tiles / (2.0 * ncu));
-            const double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
-            if (cost < best) { best = cost; T = t; }
+        for (const Cand& cd : cands) {
+            if (cd.v != 0 && !auto_variant) continue;
+            const Variant& Vc = kVariants[cd.v];
+            for (int t = 2; t <= 12; ++t) {
+                if ((M > Vc.RI && 2 * t >= Vc.RI) || (N > Vc.RJ && 2 * t >= Vc.RJ)) continue;   // no core left
+                const int a = tile_count(M, Vc.RI, t), b = tile_count(N, Vc.RJ, t);
+                if (a < 1 || b < 1) continue;
+                const double tiles = (double)a * b * h->cur_nimg;
+                const double per_iter = (tiles <= ncu) ? cd.one : cd.two * std::ceil(tiles / (2.0 * ncu));
+                const double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
+                if (cost < best) { best = cost; T = t; v = cd.v; }
+            }
         }
     }
+    const Variant& V = kVariants[v];
     if (T <= 0) {
         // Large images (tools/gpu_cfg5b.py: 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
         // of 3 px/thread beat the 64x64 / 4 px variant by 7-18 %; depth 8, or 6 once the grid is
