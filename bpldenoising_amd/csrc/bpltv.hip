@@ -59,6 +59,8 @@ const Variant kVariants[] = {
     VAR(1, 2, 40, 20),  // 11: 40x40 region, 800 threads, 2 px/thread (core 24 at T = 8: 5x5 tiles per 128^2 image)
     VAR(2, 2, 20, 20),  // 12: 40x40 region, 400 threads, 4 px/thread
     VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread   (default for images larger than 256)
+    // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
+    //  8 x 1024^2 as well: none beats variant 13)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -1006,12 +1008,9 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     HIPCHK(h, hipMalloc((void**)&h->d_perimg, (size_t)O * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_scalar, 4 * sizeof(double)));
     // LDS above 64 KB needs the opt-in attribute
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 32, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(64, 64)));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<4, 4, 16, 16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(64, 64)));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&pdhg_tile_kernel<2, 2, 64, 16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pdhg_lds_bytes(128, 32)));
+    for (const Variant& V : kVariants)
+        if (V.lds > 64 * 1024)
+            HIPCHK(h, hipFuncSetAttribute(V.func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
     return BPLTV_OK;
 }
 

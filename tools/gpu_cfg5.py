@@ -10,8 +10,8 @@ ub, f = synth_batch(O, n, n, seed=3)
 jj, ii = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
 amap = 0.11 + 0.09 * np.sin(2 * np.pi * ii / n) * np.cos(2 * np.pi * jj / n)
 s = TVSolver(n, n, O); s.set_data(ub, f)
-for var in range(1, 15):
-    for T in (4, 6, 8, 10, 12):
+for var in range(1, 14):
+    for T in (6, 8, 10):
         try:
             t = []
             for _ in range(2):
