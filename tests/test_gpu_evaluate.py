@@ -419,3 +419,15 @@ def test_full_size_gradient_properties_1024(gpu_solver_cls):
     g2 = s.gradient(u, ub, 0.1)
     assert np.isclose(g2, g, rtol=1e-12), (g, g2)            # same kernels, same data: reproducible
     s.close()
+
+
+def test_large_batch_uses_the_wide_region_plan(gpu_solver_cls, oracle):
+    """From about 12 images of 128^2 the automatic plan switches to 48x48 regions (3 px per thread): same bits."""
+    ub, f = synth_batch(16, 128, 128, seed=90)
+    s = gpu_solver_cls(128, 128, 16)
+    s.set_data(ub, f)
+    u = s.denoise(0.07, maxiter=300)
+    st = s.stats()
+    assert st["tiles"] == 16 * 16 and st["tile_iters"] == 10          # 4 x 4 tiles of 48x48 per image
+    assert np.array_equal(u, oracle.pdhg(f, 0.07, maxiter=300, nthreads=8))
+    s.close()

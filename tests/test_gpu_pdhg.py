@@ -43,7 +43,7 @@ def test_every_kernel_variant_and_fusion_depth_is_bit_identical(gpu_solver_cls, 
     u0 = oracle.pdhg(f, 0.08, maxiter=97)
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
-    for variant in range(1, 11):
+    for variant in range(1, 14):
         for T_ in (1, 2, 5, 8):
             for chains in (1, 2):
                 for graph in (0, 1):
@@ -157,7 +157,9 @@ def test_full_size_properties_1024(gpu_solver_cls):
     assert s.stats()["bytes_per_px_iter"] == 64.0
     u_b = s.denoise(amap, maxiter=64, variant=1, tile_iters=4)
     u_c = s.denoise(amap, maxiter=64, variant=6, tile_iters=3, use_graph=0)
-    assert np.array_equal(u_a, u_b) and np.array_equal(u_a, u_c)
+    u_d = s.denoise(amap, maxiter=64)                      # automatic plan: 48x48 regions (variant 13)
+    assert s.stats()["tiles"] == 8 * 32 * 32
+    assert np.array_equal(u_a, u_b) and np.array_equal(u_a, u_c) and np.array_equal(u_a, u_d)
     s.denoise(amap, maxiter=256, fetch=False)
     g256 = s.duality_gap()
     assert np.all(g64 >= 0) and np.all(g256 >= 0) and np.all(g256 < g64)
