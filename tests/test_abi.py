@@ -110,3 +110,26 @@ def test_plain_c_program_links_against_the_abi(tmp_path):
            "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-lm"]
     subprocess.check_call(cmd)
     assert exe.exists()
+
+
+def test_julia_glue_struct_matches_the_header():
+    """integration/TVLearningFunctionHIP.jl restates `bpltv_params`: same fields, same order, and it only
+    calls symbols the header declares."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "bpltv.h")).read()
+    body = re.search(r"typedef struct bpltv_params \{(.*?)\} bpltv_params;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1]
+        c_fields += [re.sub(r"\[.*\]", "", n).strip() for n in names.split(",")]
+    jl = open(os.path.join(ROOT, "integration", "TVLearningFunctionHIP.jl")).read()
+    jbody = re.search(r"struct BpltvParams\n(.*?)\nend", jl, re.S).group(1)
+    j_fields = re.findall(r"(\w+)::", jbody)
+    assert j_fields == c_fields, (j_fields, c_fields)
+    declared = set(re.findall(r"\b(bpltv_\w+)\s*\(", hdr))
+    for sym in re.findall(r":(bpltv_\w+), libbpltv", jl):
+        assert sym in declared, sym
