@@ -12,8 +12,8 @@
 //   hb2_update_kernel  A22 -= P P^T on the lower 64x64 tiles of the trailing bw x bw block (MFMA),
 //                      and L11, P copied into the band
 // and per panel one launch of hb2_fwd_kernel / hb2_bwd_kernel per substitution.  (A first version with
-// 32-column panels, a register Cholesky and scalar updates cost 1.6 us per column and 3.5 s per
-// 8 x 1024^2 gradient; these kernels: 2.2 s with the 64-column substitutions, see DESIGN.md.)
+// 32-column panels, a register Cholesky, scalar updates and 64-column substitutions cost 3.5 s per
+// 8 x 1024^2 gradient; these kernels 1.25-1.4 s)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "adjoint_kernels.hpp"
