@@ -368,7 +368,7 @@ __device__ __forceinline__ bool bg_decode(unsigned id, unsigned P, int nt, unsig
 
 // XA_j = Linv_j C_a,  XB_j = Linv_j C_j^T, both orientations stored.
 // grid bg_grid(2*nelim*O, nt), nt = ceil(MP/64); block BG_T.
-__global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ Linv, const double* __restrict__ C,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void bcr_x_kernel(const double* __restrict__ Linv, const double* __restrict__ C,
                                                      double* __restrict__ XA, double* __restrict__ XAT,
                                                      double* __restrict__ XB, double* __restrict__ XBT, int N,
                                                      int O, int MP, int s) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(BG_T) void bcr_x_kernel(const double* __restrict__ 
 //   which 0:  D_a -= XA_{a+s}^T XA_{a+s} + XB_{a-s}^T XB_{a-s}
 //   which 1:  C_a  = -XB_{a+s}^T XA_{a+s}                       (new coupling of a+2s with a)
 // grid bg_grid(2*nsurv*O, nt); block BG_T.
-__global__ __launch_bounds__(BG_T) void bcr_upd_kernel(double* __restrict__ D, double* __restrict__ C,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void bcr_upd_kernel(double* __restrict__ D, double* __restrict__ C,
                                                        const double* __restrict__ XA, const double* __restrict__ XAT,
                                                        const double* __restrict__ XB, const double* __restrict__ XBT,
                                                        int N, int O, int MP, int s) {

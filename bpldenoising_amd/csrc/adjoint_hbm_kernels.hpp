@@ -119,7 +119,7 @@ __device__ __forceinline__ void hb2_mma_chunk(const double* __restrict__ As, con
 }
 
 // P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2, O), block BG_T.
-__global__ __launch_bounds__(BG_T) void hb2_trsm_kernel(const double* __restrict__ band, int M, int N, int k0,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void hb2_trsm_kernel(const double* __restrict__ band, int M, int N, int k0,
                                                         int npanel, const double* __restrict__ Linv,
                                                         double* __restrict__ P, int bwp) {
     __shared__ double lds[BG_LDS];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BG_T) void hb2_trsm_kernel(const double* __restrict
 // copies L11.  grid (nt (nt+1) / 2, O), nt = ceil(bw/64); block BG_T.
 // tile0: index of the first tile of this launch (0: the three tiles of the next panel's diagonal block and
 // the L11 copy -- the next hb2_potrf_kernel only needs these; 3: the rest, which runs beside it).
-__global__ __launch_bounds__(BG_T) void hb2_update_kernel(double* __restrict__ band, int M, int N, int k0,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int M, int N, int k0,
                                                           const double* __restrict__ L11, const double* __restrict__ P,
                                                           int bwp, int tile0) {
     __shared__ double lds[BG_LDS];
