@@ -24,6 +24,7 @@ class BpltvParams(C.Structure):
         ("tile_iters", C.c_int), ("use_graph", C.c_int),
         ("kappa_cap", C.c_double),
         ("refine", C.c_int),
+        ("deterministic", C.c_int),
         ("reserved", C.c_int * 5),
     ]
 
@@ -32,17 +33,23 @@ class BpltvStats(C.Structure):
     _fields_ = [
         ("M", C.c_int), ("N", C.c_int), ("O", C.c_int), ("device", C.c_int),
         ("iterations", C.c_int), ("launches", C.c_int), ("tile_iters", C.c_int), ("tiles", C.c_int),
+        ("region_i", C.c_int), ("region_j", C.c_int),
         ("graph_used", C.c_int),
         ("pdhg_ms", C.c_double), ("cost_ms", C.c_double), ("adjoint_ms", C.c_double), ("total_ms", C.c_double),
         ("bytes_per_px_iter", C.c_double), ("algorithmic_bytes", C.c_double),
-        ("last_gap", C.c_double), ("adjoint_residual", C.c_double),
-        ("reg_gradient_used", C.c_int),
-        ("reserved", C.c_int * 7),
+        ("last_gap", C.c_double), ("adjoint_residual", C.c_double), ("adjoint_residual_raw", C.c_double),
+        ("kappa_used", C.c_double),
+        ("adjoint_attempts", C.c_int), ("adjoint_method", C.c_int),
+        ("reg_gradient_used", C.c_int), ("ngpus", C.c_int),
+        ("shards", C.c_int), ("collective", C.c_int),
+        ("collective_ms", C.c_double),
+        ("reserved", C.c_int * 4),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
-        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm"}.get(self.reserved[0], "")
+        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm"}.get(self.adjoint_method, "")
+        d["collective"] = {0: "none", 1: "ncclAllReduce", 2: "ncclAllGather+ordered sum", 3: "host sum"}.get(self.collective, "")
         return d
 
 
@@ -53,6 +60,8 @@ SYMBOLS = {
     "bpltv_version": (C.c_int, []),
     "bpltv_default_params": (C.c_int, [_PP]),
     "bpltv_create": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bpltv_create_multi": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bpltv_create_sharded": (C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     "bpltv_destroy": (C.c_int, [_H]),
     "bpltv_set_data": (C.c_int, [_H, _dp, _dp]),
     "bpltv_set_data_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),

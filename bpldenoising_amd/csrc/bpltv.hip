@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
+#include "multi_gpu.hpp"
 
 using namespace bpltv;
 
@@ -85,7 +87,10 @@ struct TabKey {
 
 }  // namespace
 
+struct MultiState;   // shards, worker threads and the RCCL communicator of a multi-device handle (below)
+
 struct bpltv_handle {
+    MultiState* multi = nullptr;   // non-null: this handle only fans out to its shards (multi_gpu.hpp)
     int M = 0, N = 0, O = 0, device = 0, ncu = 0;
     size_t npx = 0, tot = 0;
     hipStream_t stream = nullptr;
@@ -108,6 +113,7 @@ struct bpltv_handle {
     double* d_alpha = nullptr;
     size_t alpha_cap = 0;
     int last_am = 1, last_an = 1;
+    double alpha_min = 0.0;       // smallest entry of the last uploaded parameter (validated on the host)
     double* d_partial = nullptr;  // [1 + am*an]
     size_t partial_cap = 0;
     double* d_red = nullptr;      // reduction scratch
@@ -139,6 +145,16 @@ struct bpltv_handle {
     double *d_u2 = nullptr, *d_ubar2 = nullptr;  // staging for bpltv_gradient
     bpltv_stats_t st;
     std::string err;
+};
+
+struct MultiState {
+    std::vector<bpltv_t*> shard;                         // ordinary single-device handles
+    std::vector<int> lo, hi, dev;                        // images [lo, hi) of shard k live on HIP device dev[k]
+    std::vector<std::unique_ptr<ShardWorker>> worker;    // one persistent host thread per shard
+    std::vector<ncclComm_t> comm;                        // ncclCommInitAll; empty when a device repeats
+    int maxloc = 0;                                      // largest shard (rows per rank of the all-gather)
+    std::vector<double*> d_rows, d_all;                  // all-gather send / receive buffers per shard
+    size_t rows_cap = 0;                                 // doubles per row buffer
 };
 
 namespace {
@@ -221,6 +237,15 @@ int upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
     if (am > h->M || an > h->N)
         return set_err(h, BPLTV_E_ARG, "alpha shape %dx%d exceeds image %dx%d", am, an, h->M, h->N);
     const size_t need = (size_t)am * an;
+    // The reference is defined for alpha >= 0 (alpha = 0: u = f); NaN/Inf or a negative ball radius has no
+    // meaning on this path and would propagate silently through 5000 iterations.
+    double amin = alpha[0];
+    for (size_t e = 0; e < need; ++e) {
+        if (!std::isfinite(alpha[e]) || alpha[e] < 0.0)
+            return set_err(h, BPLTV_E_ARG, "alpha[%zu] = %g: parameters must be finite and >= 0", e, alpha[e]);
+        if (alpha[e] < amin) amin = alpha[e];
+    }
+    h->alpha_min = amin;
     if (h->alpha_cap < need) {
         drop_graphs(h);  // captured kernels hold the old pointer
         int rc = ensure(h, &h->d_alpha, &h->alpha_cap, need);
@@ -324,7 +349,9 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             a.Odata = h->O; a.astride = h->cur_astride;
             a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
             a.img0 = lo;
+#ifdef BPLTV_EXPERIMENTS
             a.dbg = p.reserved[3];
+#endif
             const int nxt = (it == 0) ? 0 : 1 - cur;
             a.first = (it == 0) ? 1 : 0;
             a.xin = h->cur_state[cur][0]; a.y1in = h->cur_state[cur][1]; a.y2in = h->cur_state[cur][2];
@@ -380,7 +407,9 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.Odata = h->O; a.astride = h->cur_astride;
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
     a.img0 = 0;
+#ifdef BPLTV_EXPERIMENTS
     a.dbg = p.reserved[3];
+#endif
     int cur = *buf;
     for (int it = it0; it < it1; it += pl.T) {
         const int nit = std::min(pl.T, it1 - it);
@@ -423,6 +452,8 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->has_per_image = false;
     if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
     if (p.maxiter < 0) return set_err(h, BPLTV_E_ARG, "maxiter < 0");
+    if (p.rho != 0.0 && !(h->alpha_min > 0.0))
+        return set_err(h, BPLTV_E_ARG, "rho != 0 divides by alpha: every parameter entry must be > 0 (min = %g)", h->alpha_min);
     Plan pl;
     int rc = make_plan(h, p, &pl);
     if (rc) return rc;
@@ -431,6 +462,8 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (rc) return rc;
     h->st.tile_iters = pl.T;
     h->st.tiles = pl.grid;
+    h->st.region_i = kVariants[pl.variant].RI;
+    h->st.region_j = kVariants[pl.variant].RJ;
     h->st.launches = 0;
     h->st.iterations = 0;
     h->st.graph_used = 0;
@@ -560,7 +593,7 @@ int adj_alloc(bpltv_t* h) {
     HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_resn, 2 * (size_t)h->O * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_resn, 4 * (size_t)h->O * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
     h->adj_ready = true;
     return BPLTV_OK;
@@ -649,7 +682,7 @@ int band_alloc(bpltv_t* h) {
 }
 
 // ---- the three factorisations of the reduced adjoint system ----------------------
-enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3 };   // also bpltv_stats_t::reserved[0]
+enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3 };   // also bpltv_stats_t::adjoint_method
 
 // Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
 // reduction) and make sure its workspace exists.
@@ -846,7 +879,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         solve(h->d_r, h->d_p);
     }
     hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
-    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, (int)h->npx, h->d_resn);
+    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_band4, (int)h->npx, h->d_resn);
     // gradient per pixel, then per parameter
     hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
                        h->d_gpix);
@@ -864,24 +897,32 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     std::vector<int> fail(O);
-    std::vector<double> resn(2 * (size_t)O);
+    std::vector<double> resn(4 * (size_t)O);
     HIPCHK(h, hipMemcpyAsync(fail.data(), h->d_fail, sizeof(int) * O, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(resn.data(), h->d_resn, sizeof(double) * 2 * O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(resn.data(), h->d_resn, sizeof(double) * 4 * O, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
-    h->st.reserved[0] = (int)method;
-    double worst = 0.0;
+    h->st.adjoint_method = (int)method;
+    h->st.kappa_used = reg ? 0.0 : kact;
+    double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
             return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at %s %d of image %d",
                            method == ADJ_BCR ? "block" : "column", fail[k] - 1, k);
-        const double r = std::sqrt(resn[2 * k]) / (resn[2 * k + 1] > 0 ? std::sqrt(resn[2 * k + 1]) : 1.0);
-        if (r > worst) worst = r;
+        const double* q = &resn[4 * (size_t)k];
+        const double raw = std::sqrt(q[0]) / (q[1] > 0 ? std::sqrt(q[1]) : 1.0);
+        const double scl = std::sqrt(q[2]) / (q[3] > 0 ? std::sqrt(q[3]) : 1.0);
+        if (!(raw <= worst_raw)) worst_raw = raw;   // NaN-propagating max
+        if (!(scl <= worst)) worst = scl;
     }
     h->st.adjoint_residual = worst;
+    h->st.adjoint_residual_raw = worst_raw;
+    if (!(worst <= BPLTV_RESIDUAL_GATE))
+        return set_err(h, BPLTV_E_NUMERIC, "adjoint solve: scaled residual %.3e above the gate %.1e (weight %.3e, %d refinement sweeps)",
+                       worst, (double)BPLTV_RESIDUAL_GATE, kact, nref);
     return BPLTV_OK;
 }
 
@@ -890,12 +931,21 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
 // (1e12 still reproduces the hard-constraint limit to ~1e-5).
 int run_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
                  double* d_out) {
+    const bool patch = !(h->last_am == 1 && h->last_an == 1);
+    if (reg && patch && !(h->alpha_min > 0.0))
+        return set_err(h, BPLTV_E_ARG, "gradient_reg with a patch / pixel-map parameter symmetrises with sqrt(alpha): every entry must be > 0 (min = %g)", h->alpha_min);
     double scale = 1.0;
     int rc = BPLTV_OK;
+    h->st.adjoint_attempts = 0;
     for (int attempt = 0; attempt < 3; ++attempt, scale *= 1e-2) {
         rc = run_gradient_once(h, d_u, d_ubar, reg, p, d_out, scale);
+        h->st.adjoint_attempts = attempt + 1;
         if (rc != BPLTV_E_NUMERIC) break;
+        if (reg) break;   // gradient_reg has no active-set weight to reduce
     }
+    // stats.kappa_used / adjoint_attempts say which system produced the gradient; a retry that succeeded is
+    // not an error, so the message of the failed attempt does not stay behind
+    if (rc == BPLTV_OK) h->err.clear();
     return rc;
 }
 
@@ -903,6 +953,19 @@ bpltv_params resolve(const bpltv_params* p) {
     bpltv_params q;
     if (p) q = *p; else bpltv_default_params(&q);
     return q;
+}
+
+// Parameter checks shared by every entry point that takes a bpltv_params.
+int check_params(bpltv_t* h, const bpltv_params& p) {
+#ifndef BPLTV_EXPERIMENTS
+    if (p.reserved[3] != 0)
+        return set_err(h, BPLTV_E_ARG, "params.reserved[3] must be 0 (the timing-experiment switches exist in tools/ builds only)");
+#endif
+    if (!(p.tau0 > 0.0) || !(p.sigma0 > 0.0) || !std::isfinite(p.tau0) || !std::isfinite(p.sigma0))
+        return set_err(h, BPLTV_E_ARG, "tau0 and sigma0 must be positive and finite");
+    if (!(p.rho >= 0.0) || !std::isfinite(p.rho)) return set_err(h, BPLTV_E_ARG, "rho must be >= 0 and finite");
+    if (p.reserved[4] < 0 || p.reserved[4] > 2) return set_err(h, BPLTV_E_ARG, "unknown adjoint factorisation %d", p.reserved[4]);
+    return BPLTV_OK;
 }
 
 struct WallTimer {
@@ -916,6 +979,7 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
     WallTimer wt;
     HIPCHK(h, hipSetDevice(h->device));
     bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
     int rc = upload_alpha(h, alpha, am, an);
     if (rc) return rc;
     rc = run_pdhg(h, p);
@@ -942,6 +1006,309 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
     h->st.total_ms = wt.ms();
     h->has_per_image = !(am == h->M && an == h->N && !(h->M == 1 && h->N == 1));
     return BPLTV_OK;
+}
+
+
+// ============================================================================================
+// Multi-device handle (multi_gpu.hpp): every entry point fans out to the shards' worker threads.
+// ============================================================================================
+#define NCCLCHK(h, call)                                                                            \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess)                                                                      \
+            return set_err(h, BPLTV_E_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_),   \
+                           __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// Run f(k, shard k) on every shard's worker thread and wait for all of them.
+template <class F>
+int multi_run(bpltv_t* h, F f) {
+    MultiState& ms = *h->multi;
+    const int n = (int)ms.shard.size();
+    for (int k = 0; k < n; ++k) ms.worker[k]->post([&f, &ms, k]() -> int { return f(k, ms.shard[k]); });
+    int rc = BPLTV_OK, bad = -1;
+    for (int k = 0; k < n; ++k) {
+        const int r = ms.worker[k]->wait();
+        if (r != BPLTV_OK && rc == BPLTV_OK) { rc = r; bad = k; }
+    }
+    if (rc != BPLTV_OK)
+        set_err(h, rc, "shard %d (images %d..%d, device %d): %s", bad, ms.lo[bad], ms.hi[bad] - 1, ms.dev[bad],
+                ms.shard[bad] ? ms.shard[bad]->err.c_str() : "creation failed");
+    return rc;
+}
+
+void multi_free(bpltv_t* h) {
+    MultiState* ms = h->multi;
+    if (!ms) return;
+    const int n = (int)ms->shard.size();
+    if (!ms->worker.empty()) {
+        (void)multi_run(h, [ms](int k, bpltv_t* c) -> int {
+            if (k < (int)ms->d_rows.size() && ms->d_rows[k]) (void)hipFree(ms->d_rows[k]);
+            if (k < (int)ms->d_all.size() && ms->d_all[k]) (void)hipFree(ms->d_all[k]);
+            if (c) (void)bpltv_destroy(c);
+            return BPLTV_OK;
+        });
+    }
+    for (ncclComm_t c : ms->comm) (void)ncclCommDestroy(c);
+    ms->worker.clear();   // joins the threads
+    (void)n;
+    delete ms;
+    h->multi = nullptr;
+}
+
+int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nshards, int dtype) {
+    if (!out) return BPLTV_E_ARG;
+    *out = nullptr;
+    if (M < 1 || N < 1 || O < 1 || dtype != 64 || !devices || nshards < 1) return BPLTV_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BPLTV_E_HIP;
+    for (int k = 0; k < nshards; ++k)
+        if (devices[k] < 0 || devices[k] >= ndev) return BPLTV_E_ARG;
+    bpltv_t* h = new (std::nothrow) bpltv_handle();
+    if (!h) return BPLTV_E_NOMEM;
+    *out = h;   // returned even on failure so that bpltv_last_error works; caller destroys
+    h->M = M; h->N = N; h->O = O; h->device = devices[0];
+    h->npx = (size_t)M * N;
+    h->tot = h->npx * O;
+    std::memset(&h->st, 0, sizeof(h->st));
+    h->st.M = M; h->st.N = N; h->st.O = O; h->st.device = devices[0];
+    h->st.last_gap = -1.0;
+    MultiState* ms = new (std::nothrow) MultiState();
+    if (!ms) return set_err(h, BPLTV_E_NOMEM, "out of host memory");
+    h->multi = ms;
+    const int n = std::min(nshards, O);   // no empty shards: 1 image cannot use more than one GPU
+    std::set<int> distinct;
+    for (int k = 0; k < n; ++k) {
+        int lo, hi;
+        shard_range(O, n, k, &lo, &hi);
+        ms->lo.push_back(lo); ms->hi.push_back(hi); ms->dev.push_back(devices[k]);
+        ms->maxloc = std::max(ms->maxloc, hi - lo);
+        distinct.insert(devices[k]);
+        ms->shard.push_back(nullptr);
+        ms->worker.emplace_back(new ShardWorker(devices[k]));
+    }
+    ms->d_rows.assign(n, nullptr);
+    ms->d_all.assign(n, nullptr);
+    h->st.ngpus = (int)distinct.size();
+    h->st.shards = n;
+    int rc = multi_run(h, [ms, M, N](int k, bpltv_t*) -> int {
+        return bpltv_create(&ms->shard[k], M, N, ms->hi[k] - ms->lo[k], ms->dev[k], 64);
+    });
+    if (rc) return rc;
+    if ((int)distinct.size() == n) {   // one rank per device: RCCL communicator of this process
+        ms->comm.assign(n, nullptr);
+        ncclResult_t r = ncclCommInitAll(ms->comm.data(), n, ms->dev.data());
+        if (r != ncclSuccess) {
+            ms->comm.clear();
+            return set_err(h, BPLTV_E_HIP, "ncclCommInitAll over %d devices failed: %s", n, ncclGetErrorString(r));
+        }
+    }
+    return BPLTV_OK;
+}
+
+int multi_stats(bpltv_t* h) {   // aggregate the shards' statistics into h->st
+    MultiState& ms = *h->multi;
+    bpltv_stats_t a = ms.shard[0]->st;
+    a.O = h->O; a.device = ms.dev[0];
+    for (size_t k = 1; k < ms.shard.size(); ++k) {
+        const bpltv_stats_t& b = ms.shard[k]->st;
+        a.tiles += b.tiles;
+        a.launches = std::max(a.launches, b.launches);
+        a.pdhg_ms = std::max(a.pdhg_ms, b.pdhg_ms);
+        a.cost_ms = std::max(a.cost_ms, b.cost_ms);
+        a.adjoint_ms = std::max(a.adjoint_ms, b.adjoint_ms);
+        a.algorithmic_bytes += b.algorithmic_bytes;
+        a.last_gap = std::max(a.last_gap, b.last_gap);
+        a.adjoint_residual = std::max(a.adjoint_residual, b.adjoint_residual);
+        a.adjoint_residual_raw = std::max(a.adjoint_residual_raw, b.adjoint_residual_raw);
+        a.kappa_used = std::min(a.kappa_used, b.kappa_used);
+        a.adjoint_attempts = std::max(a.adjoint_attempts, b.adjoint_attempts);
+        a.iterations = std::max(a.iterations, b.iterations);
+    }
+    a.ngpus = h->st.ngpus; a.shards = h->st.shards;
+    a.collective = h->st.collective; a.collective_ms = h->st.collective_ms;
+    a.total_ms = h->st.total_ms;
+    h->st = a;
+    return BPLTV_OK;
+}
+
+int multi_set_data(bpltv_t* h, const double* ubar, const double* f) {
+    if (!ubar || !f) return set_err(h, BPLTV_E_ARG, "set_data: null pointer");
+    MultiState& ms = *h->multi;
+    const size_t npx = h->npx;
+    int rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_set_data(c, ubar + ms.lo[k] * npx, f + ms.lo[k] * npx); });
+    if (rc == BPLTV_OK) h->has_data = true;
+    return rc;
+}
+
+int multi_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out) {
+    WallTimer wt;
+    MultiState& ms = *h->multi;
+    const size_t npx = h->npx;
+    int rc = multi_run(h, [&](int k, bpltv_t* c) {
+        return bpltv_denoise(c, alpha, am, an, pp, u_out ? u_out + ms.lo[k] * npx : nullptr);
+    });
+    if (rc) return rc;
+    h->has_result = true;
+    h->st.collective = 0; h->st.collective_ms = 0.0;
+    h->st.total_ms = wt.ms();
+    return multi_stats(h);
+}
+
+// tv_op_learning_function over the shards: every device evaluates its images, then ONE collective on the
+// [cost, grad...] vector.  out: host, 1 + am*an doubles.
+int multi_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* pp,
+                   double* u_out, double* out) {
+    WallTimer wt;
+    MultiState& ms = *h->multi;
+    const int n = (int)ms.shard.size();
+    const size_t npx = h->npx, P = (size_t)am * an, np = 1 + P;
+    const bpltv_params p = resolve(pp);
+    int rc = multi_run(h, [&](int k, bpltv_t* c) {
+        return evaluate_common(c, alpha, am, an, delta, pp, u_out ? u_out + ms.lo[k] * npx : nullptr, nullptr, nullptr);
+    });
+    if (rc) return rc;
+    const bool amap = (am == h->M && an == h->N) && !(h->M == 1 && h->N == 1);
+    const bool ordered = p.deterministic != 0 && !amap;
+    const bool rccl = !ms.comm.empty();
+    WallTimer ct;
+    if (ordered) {
+        // per-image rows [cost_k, grad_k...] of every shard, added in global image order (plain left-to-right
+        // sums == what sum_final_kernel does on one device): totals bitwise independent of the sharding
+        std::vector<double> rows((size_t)n * ms.maxloc * np, 0.0);
+        if (rccl) {
+            const size_t need = (size_t)ms.maxloc * np;
+            rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+                if (ms.rows_cap < need) {
+                    if (ms.d_rows[k]) (void)hipFree(ms.d_rows[k]);
+                    if (ms.d_all[k]) (void)hipFree(ms.d_all[k]);
+                    ms.d_rows[k] = ms.d_all[k] = nullptr;
+                    HIPCHK(c, hipMalloc((void**)&ms.d_rows[k], need * sizeof(double)));
+                    HIPCHK(c, hipMalloc((void**)&ms.d_all[k], need * n * sizeof(double)));
+                }
+                hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, c->stream, c->d_perimg,
+                                   c->d_red, c->O, (int)P, ms.maxloc, ms.d_rows[k]);
+                HIPCHK(c, hipGetLastError());
+                return BPLTV_OK;
+            });
+            if (rc) return rc;
+            ms.rows_cap = std::max(ms.rows_cap, need);
+            NCCLCHK(h, ncclGroupStart());
+            for (int k = 0; k < n; ++k)
+                NCCLCHK(h, ncclAllGather(ms.d_rows[k], ms.d_all[k], need, ncclDouble, ms.comm[k], ms.shard[k]->stream));
+            NCCLCHK(h, ncclGroupEnd());
+            rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+                if (k == 0)
+                    HIPCHK(c, hipMemcpyAsync(rows.data(), ms.d_all[0], rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                return BPLTV_OK;
+            });
+            if (rc) return rc;
+            h->st.collective = 2;
+        } else {
+            rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_per_image(c, rows.data() + (size_t)k * ms.maxloc * np); });
+            if (rc) return rc;
+            h->st.collective = 3;
+        }
+        // cost: sum_final_kernel adds per-image values in image order; gradient entry q likewise
+        for (size_t e = 0; e < np; ++e) out[e] = 0.0;
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < ms.hi[k] - ms.lo[k]; ++i) {
+                const double* r = rows.data() + ((size_t)k * ms.maxloc + i) * np;
+                for (size_t e = 0; e < np; ++e) out[e] += r[e];
+            }
+    } else if (rccl) {
+        // ONE ncclAllReduce(sum, f64) over xGMI, in place on the shards' partial vectors (every rank of this
+        // single-process communicator is driven from the caller's thread, grouped)
+        NCCLCHK(h, ncclGroupStart());
+        for (int k = 0; k < n; ++k)
+            NCCLCHK(h, ncclAllReduce(ms.shard[k]->d_partial, ms.shard[k]->d_partial, np, ncclDouble, ncclSum, ms.comm[k],
+                                     ms.shard[k]->stream));
+        NCCLCHK(h, ncclGroupEnd());
+        rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+            if (k == 0)
+                HIPCHK(c, hipMemcpyAsync(out, c->d_partial, np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            return BPLTV_OK;
+        });
+        if (rc) return rc;
+        h->st.collective = 1;
+    } else {
+        // repeated devices (rehearsal): RCCL cannot hold two ranks on one device; same sum on the host
+        std::vector<double> part((size_t)n * np);
+        rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+            HIPCHK(c, hipMemcpy(part.data() + (size_t)k * np, c->d_partial, np * sizeof(double), hipMemcpyDeviceToHost));
+            return BPLTV_OK;
+        });
+        if (rc) return rc;
+        for (size_t e = 0; e < np; ++e) {
+            double acc = part[e];
+            for (int k = 1; k < n; ++k) acc += part[(size_t)k * np + e];
+            out[e] = acc;
+        }
+        h->st.collective = n > 1 ? 3 : 0;
+    }
+    h->st.collective_ms = ct.ms();
+    h->has_result = true;
+    h->has_per_image = !amap;
+    h->last_am = am; h->last_an = an;
+    h->st.total_ms = wt.ms();
+    return multi_stats(h);
+}
+
+int multi_gradient(bpltv_t* h, const double* u, const double* ubar, const double* alpha, int am, int an, int reg,
+                   const bpltv_params* pp, double* grad_out) {
+    if (!u || !ubar || !grad_out || !alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "gradient: null pointer or empty shape");
+    WallTimer wt;
+    MultiState& ms = *h->multi;
+    const int n = (int)ms.shard.size();
+    const size_t npx = h->npx, P = (size_t)am * an;
+    std::vector<double> g((size_t)n * P);
+    int rc = multi_run(h, [&](int k, bpltv_t* c) {
+        return bpltv_gradient(c, u + ms.lo[k] * npx, ubar + ms.lo[k] * npx, alpha, am, an, reg, pp, g.data() + (size_t)k * P);
+    });
+    if (rc) return rc;
+    for (size_t e = 0; e < P; ++e) {   // gradient wrappers sum per-image terms (TVLearningFunctionVec.jl:76-82,168-173)
+        double acc = g[e];
+        for (int k = 1; k < n; ++k) acc += g[(size_t)k * P + e];
+        grad_out[e] = acc;
+    }
+    h->st.total_ms = wt.ms();
+    return multi_stats(h);
+}
+
+int multi_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const bpltv_params* pp, double* cost_out,
+                double* u_out) {
+    if (!alphas || !cost_out || K < 1) return set_err(h, BPLTV_E_ARG, "sweep: null pointer or K < 1");
+    WallTimer wt;
+    MultiState& ms = *h->multi;
+    const int n = (int)ms.shard.size();
+    const size_t npx = h->npx;
+    std::vector<double> cost((size_t)n * K);
+    std::vector<std::vector<double>> ubuf(n);
+    int rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+        const size_t Ok = (size_t)(ms.hi[k] - ms.lo[k]);
+        if (u_out) ubuf[k].resize((size_t)K * Ok * npx);
+        const int r = bpltv_sweep(c, alphas, K, am, an, pp, cost.data() + (size_t)k * K, u_out ? ubuf[k].data() : nullptr);
+        if (r == BPLTV_OK && u_out)   // parameter-major [K][O][N][M]: this shard's images of every parameter block
+            for (int q = 0; q < K; ++q)
+                std::memcpy(u_out + ((size_t)q * h->O + ms.lo[k]) * npx, ubuf[k].data() + (size_t)q * Ok * npx, Ok * npx * sizeof(double));
+        return r;
+    });
+    if (rc) return rc;
+    for (int q = 0; q < K; ++q) {
+        double acc = cost[q];
+        for (int k = 1; k < n; ++k) acc += cost[(size_t)k * K + q];
+        cost_out[q] = acc;
+    }
+    h->st.total_ms = wt.ms();
+    return multi_stats(h);
+}
+
+int multi_unsupported(bpltv_t* h, const char* what) {
+    if (h->multi->shard.size() == 1) return -1;   // one shard: forward to it
+    return set_err(h, BPLTV_E_UNSUPPORTED, "%s takes a device pointer, which is ambiguous on a handle over %zu shards; use the host-array entry points",
+                   what, h->multi->shard.size());
 }
 
 }  // namespace
@@ -990,6 +1357,7 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     std::memset(&h->st, 0, sizeof(h->st));
     h->st.M = M; h->st.N = N; h->st.O = O; h->st.device = device;
     h->st.last_gap = -1.0;
+    h->st.ngpus = 1;
     *out = h;  // returned even on failure below so that bpltv_last_error works; caller destroys
     HIPCHK(h, hipSetDevice(device));
     {
@@ -1014,8 +1382,29 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     return BPLTV_OK;
 }
 
+int bpltv_create_sharded(bpltv_t** out, int M, int N, int O, const int* devices, int nshards, int dtype) {
+    return multi_create(out, M, N, O, devices, nshards, dtype);
+}
+
+int bpltv_create_multi(bpltv_t** out, int M, int N, int O, int ngpus, int dtype) {
+    if (!out) return BPLTV_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BPLTV_E_HIP;
+    if (ngpus == 0) ngpus = ndev;   // all visible devices
+    if (ngpus < 0 || ngpus > ndev) return BPLTV_E_ARG;
+    std::vector<int> devs(ngpus);
+    for (int k = 0; k < ngpus; ++k) devs[k] = k;
+    return multi_create(out, M, N, O, devs.data(), ngpus, dtype);
+}
+
 int bpltv_destroy(bpltv_t* h) {
     if (!h) return BPLTV_OK;
+    if (h->multi) {
+        multi_free(h);
+        delete h;
+        return BPLTV_OK;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
@@ -1055,18 +1444,28 @@ static int set_data_impl(bpltv_t* h, const double* ubar, const double* f, hipMem
 }
 
 int bpltv_set_data(bpltv_t* h, const double* ubar, const double* f) {
+    if (h && h->multi) return multi_set_data(h, ubar, f);
     return set_data_impl(h, ubar, f, hipMemcpyHostToDevice);
 }
 
 int bpltv_set_data_device(bpltv_t* h, const double* d_ubar, const double* d_f) {
+    if (h && h->multi) {
+        const int rc = multi_unsupported(h, "bpltv_set_data_device");
+        if (rc >= 0) return rc;
+        const int r = bpltv_set_data_device(h->multi->shard[0], d_ubar, d_f);
+        if (r) h->err = h->multi->shard[0]->err; else h->has_data = true;
+        return r;
+    }
     return set_data_impl(h, d_ubar, d_f, hipMemcpyDeviceToDevice);
 }
 
 int bpltv_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out) {
     if (!h) return BPLTV_E_ARG;
+    if (h->multi) return multi_denoise(h, alpha, am, an, pp, u_out);
     WallTimer wt;
     HIPCHK(h, hipSetDevice(h->device));
     bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
     int rc = upload_alpha(h, alpha, am, an);
     if (rc) return rc;
     rc = run_pdhg(h, p);
@@ -1086,7 +1485,8 @@ int bpltv_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta
     if (!cost_out || !grad_out) return set_err(h, BPLTV_E_ARG, "evaluate: null output pointer");
     if (am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: empty shape");
     std::vector<double> part(1 + (size_t)am * an);
-    int rc = evaluate_common(h, alpha, am, an, delta, p, u_out, nullptr, part.data());
+    int rc = h->multi ? multi_evaluate(h, alpha, am, an, delta, p, u_out, part.data())
+                      : evaluate_common(h, alpha, am, an, delta, p, u_out, nullptr, part.data());
     if (rc) return rc;
     *cost_out = part[0];
     std::memcpy(grad_out, part.data() + 1, sizeof(double) * (size_t)am * an);
@@ -1097,6 +1497,10 @@ int bpltv_evaluate_partial(bpltv_t* h, const double* alpha, int am, int an, doub
                            double* u_out, double* partial_out) {
     if (!h) return BPLTV_E_ARG;
     if (!partial_out) return set_err(h, BPLTV_E_ARG, "evaluate_partial: null output pointer");
+    if (h->multi) {   // the "partial" of a multi-device handle is the total over its shards
+        if (!alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
+        return multi_evaluate(h, alpha, am, an, delta, p, u_out, partial_out);
+    }
     return evaluate_common(h, alpha, am, an, delta, p, u_out, nullptr, partial_out);
 }
 
@@ -1104,11 +1508,25 @@ int bpltv_evaluate_device(bpltv_t* h, const double* alpha, int am, int an, doubl
                           double* d_partial) {
     if (!h) return BPLTV_E_ARG;
     if (!d_partial) return set_err(h, BPLTV_E_ARG, "evaluate_device: null output pointer");
+    if (h->multi) {
+        const int rc = multi_unsupported(h, "bpltv_evaluate_device");
+        if (rc >= 0) return rc;
+        const int r = bpltv_evaluate_device(h->multi->shard[0], alpha, am, an, delta, p, d_partial);
+        if (r) h->err = h->multi->shard[0]->err; else { h->has_result = true; multi_stats(h); }
+        return r;
+    }
     return evaluate_common(h, alpha, am, an, delta, p, nullptr, d_partial, nullptr);
 }
 
 int bpltv_u_device(bpltv_t* h, const double** d_u) {
     if (!h || !d_u) return BPLTV_E_ARG;
+    if (h->multi) {
+        const int rc = multi_unsupported(h, "bpltv_u_device");
+        if (rc >= 0) return rc;
+        const int r = bpltv_u_device(h->multi->shard[0], d_u);
+        if (r) h->err = h->multi->shard[0]->err;
+        return r;
+    }
     if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     *d_u = h->d_state[h->result_buf][0];
     return BPLTV_OK;
@@ -1116,6 +1534,13 @@ int bpltv_u_device(bpltv_t* h, const double** d_u) {
 
 int bpltv_copy_u_device(bpltv_t* h, double* d_dst) {
     if (!h || !d_dst) return BPLTV_E_ARG;
+    if (h->multi) {
+        const int rc = multi_unsupported(h, "bpltv_copy_u_device");
+        if (rc >= 0) return rc;
+        const int r = bpltv_copy_u_device(h->multi->shard[0], d_dst);
+        if (r) h->err = h->multi->shard[0]->err;
+        return r;
+    }
     if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(d_dst, h->d_state[h->result_buf][0], h->tot * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1126,6 +1551,11 @@ int bpltv_copy_u_device(bpltv_t* h, double* d_dst) {
 
 int bpltv_duality_gap(bpltv_t* h, double* gap_out) {
     if (!h || !gap_out) return BPLTV_E_ARG;
+    if (h->multi) {
+        MultiState& ms = *h->multi;
+        const int rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_duality_gap(c, gap_out + ms.lo[k]); });
+        return rc ? rc : multi_stats(h);
+    }
     if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     HIPCHK(h, hipSetDevice(h->device));
     double gmax = 0.0;
@@ -1137,6 +1567,8 @@ int bpltv_duality_gap(bpltv_t* h, double* gap_out) {
 
 int bpltv_grad_fwd(bpltv_t* h, const double* x, double* d1, double* d2) {
     if (!h || !x || !d1 || !d2) return BPLTV_E_ARG;
+    if (h->multi)   // one image: the first shard's device
+        return multi_run(h, [&](int k, bpltv_t* c) { return k == 0 ? bpltv_grad_fwd(c, x, d1, d2) : BPLTV_OK; });
     HIPCHK(h, hipSetDevice(h->device));
     const size_t n = h->npx;
     int rc = ensure(h, &h->d_red, &h->red_cap, 3 * n);
@@ -1154,6 +1586,8 @@ int bpltv_grad_fwd(bpltv_t* h, const double* x, double* d1, double* d2) {
 
 int bpltv_grad_fwd_adjoint(bpltv_t* h, const double* y1, const double* y2, double* out) {
     if (!h || !y1 || !y2 || !out) return BPLTV_E_ARG;
+    if (h->multi)
+        return multi_run(h, [&](int k, bpltv_t* c) { return k == 0 ? bpltv_grad_fwd_adjoint(c, y1, y2, out) : BPLTV_OK; });
     HIPCHK(h, hipSetDevice(h->device));
     const size_t n = h->npx;
     int rc = ensure(h, &h->d_red, &h->red_cap, 3 * n);
@@ -1173,10 +1607,12 @@ int bpltv_gradient(bpltv_t* h, const double* u, const double* ubar, const double
                    const bpltv_params* pp, double* grad_out) {
     if (h) h->has_per_image = false;
     if (!h) return BPLTV_E_ARG;
+    if (h->multi) return multi_gradient(h, u, ubar, alpha, am, an, reg, pp, grad_out);
     if (!u || !ubar || !grad_out) return set_err(h, BPLTV_E_ARG, "gradient: null pointer");
     WallTimer wt;
     HIPCHK(h, hipSetDevice(h->device));
     bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
     int rc = upload_alpha(h, alpha, am, an);
     if (rc) return rc;
     if (!h->d_u2) {
@@ -1197,12 +1633,14 @@ int bpltv_gradient(bpltv_t* h, const double* u, const double* ubar, const double
 int bpltv_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const bpltv_params* pp, double* cost_out,
                 double* u_out) {
     if (!h) return BPLTV_E_ARG;
+    if (h->multi) return multi_sweep(h, alphas, K, am, an, pp, cost_out, u_out);
     if (!alphas || !cost_out || K < 1) return set_err(h, BPLTV_E_ARG, "sweep: null pointer or K < 1");
     if (am < 1 || an < 1 || am > h->M || an > h->N) return set_err(h, BPLTV_E_ARG, "sweep: bad parameter shape %dx%d", am, an);
     if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
     WallTimer wt;
     HIPCHK(h, hipSetDevice(h->device));
     bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
     p.check_every = 0;  // the gap kernels address the dataset context only
     const size_t nimg = (size_t)K * h->O, npar = (size_t)am * an;
     if (h->sweep_cap < nimg) {
@@ -1217,6 +1655,13 @@ int bpltv_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const b
         HIPCHK(h, hipMalloc((void**)&h->d_sweep_cost, nimg * sizeof(double)));
         h->sweep_cap = nimg;
     }
+    double amin = alphas[0];
+    for (size_t e = 0; e < (size_t)K * npar; ++e) {
+        if (!std::isfinite(alphas[e]) || alphas[e] < 0.0)
+            return set_err(h, BPLTV_E_ARG, "sweep: alphas[%zu] = %g: parameters must be finite and >= 0", e, alphas[e]);
+        if (alphas[e] < amin) amin = alphas[e];
+    }
+    h->alpha_min = amin;
     // all K parameter blocks live in the alpha buffer; problem k*O + i uses block k and image i
     if (h->alpha_cap < K * npar) {
         drop_graphs(h);
@@ -1261,6 +1706,13 @@ int bpltv_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const b
 
 int bpltv_per_image(bpltv_t* h, double* out) {
     if (!h || !out) return BPLTV_E_ARG;
+    if (h->multi) {
+        if (!h->has_per_image)
+            return set_err(h, BPLTV_E_UNSUPPORTED, "per-image pieces exist after evaluate with a scalar or patch parameter only");
+        MultiState& ms = *h->multi;
+        const size_t W = 1 + (size_t)h->last_am * h->last_an;
+        return multi_run(h, [&](int k, bpltv_t* c) { return bpltv_per_image(c, out + ms.lo[k] * W); });
+    }
     if (!h->has_per_image)
         return set_err(h, BPLTV_E_UNSUPPORTED, "per-image pieces exist after evaluate with a scalar or patch parameter only");
     HIPCHK(h, hipSetDevice(h->device));

@@ -49,8 +49,18 @@ struct PdhgArgs {
     int Odata;  // images in the dataset; image `img` of the solve uses f[img % Odata] and the
                 // parameter block alpha + (img / Odata) * astride (parameter sweeps: K*Odata problems)
     int astride;
-    int dbg;    // timing experiments only (results are wrong): 1 skip state loads, 2 skip stores, 4 no iterations
+#ifdef BPLTV_EXPERIMENTS
+    int dbg;    // timing experiments of tools/ builds only (results are wrong): 1 skip state loads, 2 skip
+                // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads.  The product
+                // library is compiled without this field and without the branches it feeds.
+#endif
 };
+
+#ifdef BPLTV_EXPERIMENTS
+#define BPLTV_DBG(A) ((A).dbg)
+#else
+#define BPLTV_DBG(A) 0
+#endif
 
 // 1-D tiling with halo: region length R, halo T, image length L.  Tile a covers region
 // [o, o+R) and owns (writes back) the core [c0, c1).  Image borders need no halo (Neumann).
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     const size_t fbase = (size_t)(img % A.Odata) * M * N;    // dataset planes
     const double* __restrict__ alpha = A.alpha + (size_t)(img / A.Odata) * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
-    const bool first = (A.first != 0) || (A.dbg & 1);
+    const bool first = (A.first != 0) || (BPLTV_DBG(A) & 1);
 
     // ---- prologue: every global load is issued before the first use (one memory round trip).
     // Out-of-image pixels read a clamped in-image address and are zeroed afterwards.
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                if (A.dbg & 64) {  // experiment: non-temporal loads
+                if (BPLTV_DBG(A) & 64) {  // experiment: non-temporal loads
                     x[pj][pi] = __builtin_nontemporal_load(&A.xin[gidx[pj][pi]]);
                     y1[pj][pi] = __builtin_nontemporal_load(&A.y1in[gidx[pj][pi]]);
                     y2[pj][pi] = __builtin_nontemporal_load(&A.y2in[gidx[pj][pi]]);
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     __syncthreads();
 
     const double rho = A.rho;
-    const int nit = (A.dbg & 4) ? 0 : A.nit;
+    const int nit = (BPLTV_DBG(A) & 4) ? 0 : A.nit;
     // Neumann border without a select in the loop: at the last image row/column (and outside the
     // image) the "neighbour" read is redirected to the pixel's own xbar cell, so the forward
     // difference is exactly +0.  The LDS offsets are computed once per launch.
@@ -317,13 +327,13 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pi = 0; pi < PI; ++pi) {
             const int li = ti + TI * pi, lj = tj + TJ * pj;
             const int gi = oi + li, gj = oj + lj;
-            if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(A.dbg & 2)) {
+            if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(BPLTV_DBG(A) & 2)) {
                 const size_t idx = base + gi + (size_t)M * gj;
-                if (A.dbg & 16) {  // experiment: non-temporal stores
+                if (BPLTV_DBG(A) & 16) {  // experiment: non-temporal stores
                     __builtin_nontemporal_store(x[pj][pi], &A.xout[idx]);
                     __builtin_nontemporal_store(y1[pj][pi], &A.y1out[idx]);
                     __builtin_nontemporal_store(y2[pj][pi], &A.y2out[idx]);
-                } else if (!(A.dbg & 32)) {
+                } else if (!(BPLTV_DBG(A) & 32)) {
                     // write-through (sc1) stores: the state of this launch is read next by workgroups
                     // on other XCDs, so it has to reach memory anyway; writing through while the
                     // kernel still runs leaves no dirty L2 lines for the end-of-kernel release

@@ -21,9 +21,12 @@
  *        M x N  per-pixel map.   grad has the same shape (src/TRBox.jl:37-39,167,237).
  *   - Host pointers are read/written during the call only; the library keeps no host pointer.
  *     One call in flight per handle; calls block until the device work is complete.
- *   - One handle drives one GPU.  Multi-GPU = one process (or handle) per GPU, images sharded by
- *     the host layer, one all-reduce of the [cost, grad...] partial vector (bpltv_evaluate_partial /
- *     bpltv_evaluate_device; bpltv_per_image for sharding-independent sums); see INTEGRATION.md.
+ *   - bpltv_create drives one GPU.  bpltv_create_multi drives several from ONE host thread (the single
+ *     Julia task of src/TRBox.jl:192-273): images block-sharded over the devices, one worker thread and
+ *     stream per device inside the library, one RCCL collective over xGMI per evaluation on the
+ *     [cost, grad...] vector; every other entry point takes either kind of handle.  A host that prefers
+ *     one process per GPU shards the images itself and all-reduces bpltv_evaluate_partial /
+ *     bpltv_evaluate_device (bpltv_per_image for sharding-independent sums); see INTEGRATION.md.
  */
 #ifndef BPLTV_H
 #define BPLTV_H
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BPLTV_VERSION 1
+#define BPLTV_VERSION 2
 
 enum {
     BPLTV_OK = 0,
@@ -67,11 +70,16 @@ typedef struct bpltv_params {
     double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
     int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3 for the
                             scalar gradient, 2 for patch / pixel-map parameters and gradient_reg)  */
+    int deterministic;   /* multi-GPU handles, scalar / patch parameters: 1 = all-gather the per-image rows
+                            [cost_k, grad_k...] and add them in global image order, so that cost and grad are
+                            bitwise the same for every number of GPUs (and equal to a single handle's);
+                            0 (default) = one all-reduce(sum) of the per-device partial vectors           */
     int reserved[5];     /* tuning / measurement knobs, 0 = default:
                             [0] PDHG kernel variant (1-based index into the variant table of bpltv.hip)
                             [1] number of independent launch chains (image groups replayed concurrently)
                             [2] 1 = replay those chains one after the other (isolated kernel timing)
-                            [3] timing-experiment bit mask (results are wrong when set; see PdhgArgs::dbg)
+                            [3] must be 0 (BPLTV_E_ARG otherwise); timing-experiment switches exist only in
+                                tools/ builds compiled with -DBPLTV_EXPERIMENTS
                             [4] adjoint factorisation: 0 automatic, 1 banded Cholesky, 2 block cyclic reduction
                                 (M <= 128, N >= 2; BPLTV_E_UNSUPPORTED otherwise)                   */
 } bpltv_params;
@@ -82,6 +90,8 @@ typedef struct bpltv_stats {
     int launches;              /* PDHG kernel launches of that call                               */
     int tile_iters;            /* fused iterations per launch actually used                       */
     int tiles;                 /* workgroups per PDHG launch                                      */
+    int region_i, region_j;    /* pixels one workgroup computes per fused iteration (core + halo): with tiles
+                                  and tile_iters this gives the redundancy of the temporal blocking         */
     int graph_used;
     double pdhg_ms;            /* HIP-event time of the PDHG launch sequence (device)            */
     double cost_ms;
@@ -90,11 +100,28 @@ typedef struct bpltv_stats {
     double bytes_per_px_iter;  /* algorithmic bytes: 56 (scalar/patch alpha) or 64 (alpha map)    */
     double algorithmic_bytes;  /* bytes_per_px_iter * M*N*O * iterations                          */
     double last_gap;           /* max over images of the duality gap if it was computed, else -1  */
-    double adjoint_residual;   /* max over images of ||rhs - A p|| / ||rhs|| after refinement     */
+    double adjoint_residual;   /* max over images of ||D^-1/2 (rhs - A p)|| / ||D^-1/2 rhs||, D = diag(A), after
+                                  refinement: the quality gate of the adjoint solve (<= 1e-8 on a correct
+                                  solve; above BPLTV_RESIDUAL_GATE the call fails with BPLTV_E_NUMERIC)   */
+    double adjoint_residual_raw; /* the same without the diagonal scaling: dominated by the rounding of
+                                  the 1e14-weighted active rows, informational only                   */
+    double kappa_used;         /* active-set weight of the adjoint system that produced the returned
+                                  gradient: 1/eps() capped by kappa_cap (scalar), 1/sqrt(eps()) (patch),
+                                  times 1e-2 per retry; 0 for gradient_reg                             */
+    int adjoint_attempts;      /* factorisations tried by the last gradient: 1 = no breakdown, 2..3 = the
+                                  weight was reduced by 1e-2 per retry after a non-positive pivot      */
+    int adjoint_method;        /* 1 banded Cholesky (LDS window), 2 block cyclic reduction,
+                                  3 banded Cholesky (HBM band)                                         */
     int reg_gradient_used;     /* 1 if the last evaluate took the gradient_reg branch             */
-    int reserved[7];           /* [0] factorisation of the last adjoint solve: 1 banded Cholesky (LDS window),
-                                  2 block cyclic reduction, 3 banded Cholesky (HBM band)              */
+    int ngpus;                 /* distinct devices behind this handle (1 for bpltv_create)        */
+    int shards;                /* image shards (= worker threads) behind this handle              */
+    int collective;            /* last evaluate of a multi handle: 0 none (one shard), 1 ncclAllReduce,
+                                  2 ncclAllGather + ordered sum, 3 host sum (repeated devices)     */
+    double collective_ms;      /* host wall time of that collective (launch + completion)        */
+    int reserved[4];
 } bpltv_stats_t;
+
+#define BPLTV_RESIDUAL_GATE 1e-6
 
 /* Fill *p with the reference defaults (src/TVLearningFunctionVec.jl:33-43, delta_t 1e-6). */
 int bpltv_default_params(bpltv_params *p);
@@ -102,6 +129,19 @@ int bpltv_default_params(bpltv_params *p);
 /* Create a solver for O images of size M x N on HIP device `device` (-1 = current device).
  * dtype: 64 (Float64, the reference's arithmetic, src/TVLearningFunctionVec.jl:8-9). */
 int bpltv_create(bpltv_t **h, int M, int N, int O, int device, int dtype);
+/* The same over `ngpus` devices (0 = all visible; devices 0..ngpus-1) driven from one host thread -- the
+ * form SURVEY section 8(b)/(e) specifies for the single Julia task of src/TRBox.jl:192-273.  Images
+ * [lo_k, hi_k) = block distribution of O over min(ngpus, O) shards (the first O % shards get one more);
+ * communicator from ncclCommInitAll; per evaluation ONE RCCL collective on [cost, grad...] (1 + am*an
+ * doubles): ncclAllReduce(sum, f64), or ncclAllGather of the per-image rows when params.deterministic.
+ * set_data / denoise / evaluate / gradient / sweep / per_image / duality_gap take and return whole-batch
+ * host arrays exactly as with bpltv_create (each device copies its slice); the device-pointer entry points
+ * (set_data_device, evaluate_device, u_device, copy_u_device) return BPLTV_E_UNSUPPORTED on more than one shard. */
+int bpltv_create_multi(bpltv_t **h, int M, int N, int O, int ngpus, int dtype);
+/* Explicit placement: shard k of `nshards` runs on HIP device devices[k].  A device may appear more than
+ * once (rehearsal of the sharded path on one GPU); RCCL cannot put two ranks on one device, so the collective
+ * is then replaced by the same sum / ordered sum on the host. */
+int bpltv_create_sharded(bpltv_t **h, int M, int N, int O, const int *devices, int nshards, int dtype);
 int bpltv_destroy(bpltv_t *h);
 
 /* Upload the dataset (ubar, f) once; it is identical for every evaluation of a run

@@ -8,6 +8,13 @@ export tv_op_learning_function, denoise
 
 const libbpltv = "libbpltv"            # on LD_LIBRARY_PATH, or an absolute path
 
+# Devices behind the handle: 0 = every visible MI355X (bpltv_create_multi shards the images over them and
+# all-reduces [cost, grad...] with RCCL inside the library); 1 = a single GPU.  One Julia task drives all of
+# them -- the structure of src/TRBox.jl:192-273 does not change.
+const BPLTV_NGPUS = parse(Int, get(ENV, "BPLTV_NGPUS", "0"))
+# 1: totals bitwise independent of the number of GPUs (all-gather of per-image rows, added in image order)
+const BPLTV_DETERMINISTIC = parse(Int, get(ENV, "BPLTV_DETERMINISTIC", "0"))
+
 # struct bpltv_params (include/bpltv.h) -- field order and types must match
 struct BpltvParams
     rho::Cdouble; tau0::Cdouble; sigma0::Cdouble
@@ -18,13 +25,19 @@ struct BpltvParams
     tile_iters::Cint; use_graph::Cint
     kappa_cap::Cdouble
     refine::Cint
+    deterministic::Cint
     reserved::NTuple{5,Cint}
 end
 
 mutable struct BpltvHandle
     ptr::Ptr{Cvoid}
     M::Int; N::Int; O::Int
-    data_id::UInt                      # objectid of the dataset currently resident on the GPU
+    # The dataset currently resident on the GPUs.  The arrays themselves are kept (not their objectid): a
+    # reference held here keeps them alive, so a later dataset cannot be allocated at the same address and
+    # pass for this one after a GC; identity is compared with `===`.
+    ū::Union{Nothing,Array{Float64,3}}
+    f::Union{Nothing,Array{Float64,3}}
+    fingerprint::Tuple{Float64,Float64}   # (sum(ū), sum(f)) at upload time: catches in-place edits
 end
 
 function bpltv_check(h::BpltvHandle, rc::Cint)
@@ -33,13 +46,13 @@ function bpltv_check(h::BpltvHandle, rc::Cint)
     error("libbpltv error $rc: $msg")  # reference behaviour: exceptions propagate
 end
 
-function BpltvHandle(M, N, O; device = -1)
+function BpltvHandle(M, N, O; ngpus = BPLTV_NGPUS)
     p = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:bpltv_create, libbpltv), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
-               p, M, N, O, device, 64)
-    h = BpltvHandle(p[], M, N, O, 0)
-    bpltv_check(h, rc)
+    rc = ccall((:bpltv_create_multi, libbpltv), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint),
+               p, M, N, O, ngpus, 64)
+    h = BpltvHandle(p[], M, N, O, nothing, nothing, (NaN, NaN))
     finalizer(x -> ccall((:bpltv_destroy, libbpltv), Cint, (Ptr{Cvoid},), x.ptr), h)
+    bpltv_check(h, rc)
     return h
 end
 
@@ -52,24 +65,25 @@ function default_params(; kwargs...)
     return BpltvParams(get_(:ρ, p.rho), get_(:τ₀, p.tau0), get_(:σ₀, p.sigma0),
                        get_(:accel, p.accel != 0) ? 1 : 0, get_(:maxiter, p.maxiter),
                        get_(:Δt, p.delta_t), p.check_every, p.gap_tol, p.tile_iters, p.use_graph,
-                       p.kappa_cap, p.refine, p.reserved)
+                       p.kappa_cap, p.refine, BPLTV_DETERMINISTIC, p.reserved)
 end
 
 const _handle = Ref{Union{Nothing,BpltvHandle}}(nothing)
 
 # One handle per dataset: bilevel_learn passes the same `ds` to every evaluation
-# (src/TRBox.jl:210,227), so the images are uploaded once.
+# (src/TRBox.jl:210,227), so the images are uploaded once.  A different array object, or the same object
+# with edited content, is uploaded again.
 function handle_for(ū::Array{Float64,3}, f::Array{Float64,3})
     M, N, O = size(f)
     h = _handle[]
     if h === nothing || (h.M, h.N, h.O) != (M, N, O)
         h = BpltvHandle(M, N, O); _handle[] = h
     end
-    id = hash((objectid(ū), objectid(f)))
-    if h.data_id != id
+    fp = (sum(ū), sum(f))
+    if !(h.ū === ū && h.f === f && h.fingerprint == fp)
         GC.@preserve ū f bpltv_check(h, ccall((:bpltv_set_data, libbpltv), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h.ptr, ū, f))
-        h.data_id = id
+        h.ū = ū; h.f = f; h.fingerprint = fp
     end
     return h
 end

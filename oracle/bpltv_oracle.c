@@ -142,6 +142,53 @@ static inline double rsqrt_nr(double n2)
 
 BPLO_API double bplo_rsqrt_nr(double n2) { return rsqrt_nr(n2); }
 
+/* One primal pass / one dual pass over the columns [j0, j1) of one image.  The primal pass reads y of the
+ * previous iteration only, the dual pass reads xb of the current one only, so column blocks of a pass are
+ * independent (used by bplo_pdhg_rows). */
+static inline void pdhg_x_pass(int M, int j0, int j1, const double *f, const double *y1, const double *y2,
+                               double tau, double omega, double inv1ptau, double opw, double *x, double *xb)
+{
+    for (int j = j0; j < j1; ++j)
+        for (int i = 0; i < M; ++i) {
+            size_t k = i + (size_t)M * j;
+            double y1m = (i > 0) ? y1[k - 1] : 0.0;
+            double y2m = (j > 0) ? y2[k - M] : 0.0;
+            double div = (y1m - y1[k]) + (y2m - y2[k]);
+            double t = div - f[k];
+            double xo = x[k];
+            double xn = fma(-tau, t, xo) * inv1ptau;
+            xb[k] = fma(-omega, xo, opw * xn);
+            x[k] = xn;
+        }
+}
+
+static inline void pdhg_y_pass(int M, int N, int j0, int j1, const double *alpha, int am, int an,
+                               const double *xb, double sigma, double rho, double *y1, double *y2)
+{
+    for (int j = j0; j < j1; ++j)
+        for (int i = 0; i < M; ++i) {
+            size_t k = i + (size_t)M * j;
+            double d1 = (i < M - 1) ? xb[k + 1] - xb[k] : 0.0;
+            double d2 = (j < N - 1) ? xb[k + M] - xb[k] : 0.0;
+            double a = alpha_at(alpha, am, an, M, N, i, j);
+            double y1n = fma(sigma, d1, y1[k]);
+            double y2n = fma(sigma, d2, y2[k]);
+            if (rho != 0.0) {
+                double den = 1.0 + sigma * rho / a;
+                y1n = y1n / den;
+                y2n = y2n / den;
+            }
+            double n2 = fma(y2n, y2n, y1n * y1n);
+            if (n2 > a * a) {
+                double v = a * rsqrt_nr(n2);
+                y1n = y1n * v;
+                y2n = y2n * v;
+            }
+            y1[k] = y1n;
+            y2[k] = y2n;
+        }
+}
+
 static void pdhg_image(int M, int N, const double *f, const double *alpha, int am, int an,
                        const double *tab, int maxiter, double rho, double *x, double *y1, double *y2,
                        double *xb)
@@ -153,41 +200,55 @@ static void pdhg_image(int M, int N, const double *f, const double *alpha, int a
     for (int it = 0; it < maxiter; ++it) {
         const double tau = tab[5 * it], sigma = tab[5 * it + 1], omega = tab[5 * it + 2];
         const double inv1ptau = tab[5 * it + 3], opw = tab[5 * it + 4];
-        for (int j = 0; j < N; ++j)
-            for (int i = 0; i < M; ++i) {
-                size_t k = i + (size_t)M * j;
-                double y1m = (i > 0) ? y1[k - 1] : 0.0;
-                double y2m = (j > 0) ? y2[k - M] : 0.0;
-                double div = (y1m - y1[k]) + (y2m - y2[k]);
-                double t = div - f[k];
-                double xo = x[k];
-                double xn = fma(-tau, t, xo) * inv1ptau;
-                xb[k] = fma(-omega, xo, opw * xn);
-                x[k] = xn;
+        pdhg_x_pass(M, 0, N, f, y1, y2, tau, omega, inv1ptau, opw, x, xb);
+        pdhg_y_pass(M, N, 0, N, alpha, am, an, xb, sigma, rho, y1, y2);
+    }
+}
+
+/* The same recurrence with the work of ONE iteration spread over images x column blocks ("OpenMP over
+ * images then rows"): all threads sweep the primal pass, barrier, the dual pass,
+ * barrier.  Same per-pixel operations as pdhg_image, hence the same bits.  Used by bench.py's cpu_baseline
+ * leg so that "all cores" can mean the host's cores even for a 10-image batch. */
+BPLO_API int bplo_pdhg_rows(int M, int N, int O, const double *f, const double *alpha, int am, int an,
+                            double rho, double tau0, double sigma0, int accel, int maxiter, double *x_out,
+                            int nthreads, int colblock)
+{
+    if (M < 1 || N < 1 || O < 1 || maxiter < 0 || colblock < 1) return 1;
+    const size_t n = (size_t)M * N;
+    double *tab = (double *)malloc(sizeof(double) * 5 * (size_t)(maxiter > 0 ? maxiter : 1));
+    double *xb = (double *)malloc(n * O * sizeof(double));
+    double *y1 = (double *)calloc(n * O, sizeof(double));
+    double *y2 = (double *)calloc(n * O, sizeof(double));
+    if (!tab || !xb || !y1 || !y2) { free(tab); free(xb); free(y1); free(y2); return 2; }
+    bplo_step_table(maxiter, tau0, sigma0, accel, tab);
+    memcpy(x_out, f, n * O * sizeof(double));
+    const int nb = (N + colblock - 1) / colblock;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    for (int it = 0; it < maxiter; ++it) {
+        const double tau = tab[5 * it], sigma = tab[5 * it + 1], omega = tab[5 * it + 2];
+        const double inv1ptau = tab[5 * it + 3], opw = tab[5 * it + 4];
+#ifdef _OPENMP
+#pragma omp for collapse(2) schedule(static)
+#endif
+        for (int k = 0; k < O; ++k)
+            for (int b = 0; b < nb; ++b) {
+                const int j0 = b * colblock, j1 = (j0 + colblock < N) ? j0 + colblock : N;
+                pdhg_x_pass(M, j0, j1, f + n * k, y1 + n * k, y2 + n * k, tau, omega, inv1ptau, opw, x_out + n * k, xb + n * k);
             }
-        for (int j = 0; j < N; ++j)
-            for (int i = 0; i < M; ++i) {
-                size_t k = i + (size_t)M * j;
-                double d1 = (i < M - 1) ? xb[k + 1] - xb[k] : 0.0;
-                double d2 = (j < N - 1) ? xb[k + M] - xb[k] : 0.0;
-                double a = alpha_at(alpha, am, an, M, N, i, j);
-                double y1n = fma(sigma, d1, y1[k]);
-                double y2n = fma(sigma, d2, y2[k]);
-                if (rho != 0.0) {
-                    double den = 1.0 + sigma * rho / a;
-                    y1n = y1n / den;
-                    y2n = y2n / den;
-                }
-                double n2 = fma(y2n, y2n, y1n * y1n);
-                if (n2 > a * a) {
-                    double v = a * rsqrt_nr(n2);
-                    y1n = y1n * v;
-                    y2n = y2n * v;
-                }
-                y1[k] = y1n;
-                y2[k] = y2n;
+#ifdef _OPENMP
+#pragma omp for collapse(2) schedule(static)
+#endif
+        for (int k = 0; k < O; ++k)
+            for (int b = 0; b < nb; ++b) {
+                const int j0 = b * colblock, j1 = (j0 + colblock < N) ? j0 + colblock : N;
+                pdhg_y_pass(M, N, j0, j1, alpha, am, an, xb + n * k, sigma, rho, y1 + n * k, y2 + n * k);
             }
     }
+    free(tab); free(xb); free(y1); free(y2);
+    return 0;
 }
 
 BPLO_API int bplo_pdhg(int M, int N, int O, const double *f, const double *alpha, int am, int an,

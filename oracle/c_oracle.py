@@ -32,6 +32,9 @@ def lib():
         L.bplo_pdhg.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
         L.bplo_pdhg.restype = C.c_int
+        L.bplo_pdhg_rows.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_int, C.c_int]
+        L.bplo_pdhg_rows.restype = C.c_int
         L.bplo_cost.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
         L.bplo_cost.restype = C.c_double
         L.bplo_gap.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
@@ -94,6 +97,57 @@ def pdhg(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True,
     if return_dual:
         return x, y1.reshape(f.shape), y2.reshape(f.shape)
     return x
+
+
+_native = None
+_SO_NATIVE = os.path.join(_HERE, "libbpltv_oracle_native.so")
+
+
+def native_lib():
+    """The -O3 -march=native build of the same file, compiled on the machine that
+    runs it.  bench.py's cpu_baseline leg only: never a checker."""
+    global _native
+    if _native is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbpltv_oracle_native.so"])
+        L = C.CDLL(_SO_NATIVE)
+        L.bplo_pdhg.argtypes = lib().bplo_pdhg.argtypes
+        L.bplo_pdhg.restype = C.c_int
+        L.bplo_pdhg_rows.argtypes = lib().bplo_pdhg_rows.argtypes
+        L.bplo_pdhg_rows.restype = C.c_int
+        L.bplo_max_threads.restype = C.c_int
+        _native = L
+    return _native
+
+
+def pdhg_rows(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True, nthreads=1, colblock=8,
+              native=False):
+    """pdhg() with every iteration spread over images x column blocks (bplo_pdhg_rows): same bits in the
+    checker build; `native=True` runs the -O3 -march=native build (timing only)."""
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3)
+    L = native_lib() if native else lib()
+    rc = L.bplo_pdhg_rows(M, N, O, _p(f3), _p(a), am, an, rho, tau0, sigma0, int(accel), maxiter, _p(x),
+                          nthreads, colblock)
+    if rc:
+        raise RuntimeError("bplo_pdhg_rows rc=%d" % rc)
+    return x.reshape(f.shape)
+
+
+def pdhg_native(f, alpha, maxiter=5000, nthreads=1):
+    """bplo_pdhg of the -O3 -march=native build (timing only)."""
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3)
+    rc = native_lib().bplo_pdhg(M, N, O, _p(f3), _p(a), am, an, 0.0, 5.0, 0.99 / 5, 1, maxiter, _p(x), None, None,
+                                nthreads)
+    if rc:
+        raise RuntimeError("bplo_pdhg rc=%d" % rc)
+    return x.reshape(f.shape)
 
 
 def cost(u, ubar, per_image=False):

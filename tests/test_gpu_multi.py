@@ -1,0 +1,118 @@
+"""The single-process multi-device handle (bpltv_create_multi / bpltv_create_sharded, csrc/multi_gpu.hpp).
+
+What can be proven on a one-GPU box: (i) with ngpus = 1 the RCCL communicator (ncclCommInitAll, one rank) is
+created and the evaluate's collective really is ncclAllReduce / ncclAllGather; (ii) with several shards placed
+on device 0 (RCCL cannot hold two ranks on one device, the same reduction then runs on the host) every entry
+point shards the images, fans out to the worker threads and reassembles whole-batch results:
+`deterministic` totals are BITWISE those of one single-device handle over the whole batch, the plain sum
+agrees to rounding.  The N > 1 RCCL path itself runs only on the driver's 8-GPU node.
+"""
+import numpy as np
+import pytest
+from conftest import synth_batch
+
+pytestmark = pytest.mark.gpu
+
+P22 = np.array([[0.08, 0.12], [0.1, 0.05]])
+
+
+def _single(gpu_solver_cls, ub, f, alpha, delta=0.1, **kw):
+    O, N, M = f.shape
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    out = s.evaluate(alpha, delta, **kw)
+    rows = s.per_image() if np.size(alpha) < M * N else None
+    s.close()
+    return out, rows
+
+
+@pytest.mark.parametrize("alpha", [0.1, P22], ids=["scalar", "patch22"])
+def test_multi_handle_one_gpu_runs_rccl(gpu_solver_cls, alpha):
+    ub, f = synth_batch(3, 48, 40, seed=31)
+    (u0, c0, g0), rows0 = _single(gpu_solver_cls, ub, f, alpha, maxiter=400)
+    s = gpu_solver_cls(40, 48, 3, ngpus=1)
+    s.set_data(ub, f)
+    u, c, g = s.evaluate(alpha, 0.1, maxiter=400)
+    st = s.stats()
+    assert st["ngpus"] == 1 and st["shards"] == 1 and st["collective"] == "ncclAllReduce"
+    assert np.array_equal(u, u0) and c == c0 and np.array_equal(np.asarray(g), np.asarray(g0))
+    u, c, g = s.evaluate(alpha, 0.1, maxiter=400, deterministic=1)
+    assert s.stats()["collective"] == "ncclAllGather+ordered sum"
+    assert np.array_equal(u, u0) and c == c0 and np.array_equal(np.asarray(g), np.asarray(g0))
+    assert np.array_equal(s.per_image(), rows0)
+    s.close()
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("alpha", [0.1, P22], ids=["scalar", "patch22"])
+def test_shards_on_one_device_match_a_single_handle(gpu_solver_cls, alpha, nshards):
+    ub, f = synth_batch(5, 48, 40, seed=32)
+    (u0, c0, g0), rows0 = _single(gpu_solver_cls, ub, f, alpha, maxiter=400)
+    s = gpu_solver_cls(40, 48, 5, devices=[0] * nshards)
+    s.set_data(ub, f)
+    u, c, g = s.evaluate(alpha, 0.1, maxiter=400, deterministic=1)
+    st = s.stats()
+    assert st["shards"] == nshards and st["ngpus"] == 1 and st["collective"] == "host sum"
+    assert np.array_equal(u, u0)                         # u shards land in the caller's slices
+    assert c == c0 and np.array_equal(np.asarray(g), np.asarray(g0))   # bitwise: rows added in image order
+    assert np.array_equal(s.per_image(), rows0)
+    u, c, g = s.evaluate(alpha, 0.1, maxiter=400)        # plain sum of the per-shard partial vectors
+    assert np.array_equal(u, u0)
+    assert np.isclose(c, c0, rtol=1e-14) and np.allclose(g, g0, rtol=1e-12)
+    # gradient_reg branch, denoise, duality gap, stand-alone gradient and sweep through the same handle
+    _, _, greg = s.evaluate(alpha, 0.0, maxiter=400, deterministic=1)
+    (_, _, greg0), _ = _single(gpu_solver_cls, ub, f, alpha, delta=0.0, maxiter=400)
+    assert np.array_equal(np.asarray(greg), np.asarray(greg0))
+    assert np.array_equal(s.denoise(alpha, maxiter=123), _denoise1(gpu_solver_cls, ub, f, alpha, 123))
+    gap = s.duality_gap()
+    assert gap.shape == (5,) and (gap >= -1e-12).all()
+    assert np.allclose(s.gradient(u0, ub, alpha), g0, rtol=1e-9)
+    s.close()
+
+
+def _denoise1(gpu_solver_cls, ub, f, alpha, it):
+    O, N, M = f.shape
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u = s.denoise(alpha, maxiter=it)
+    s.close()
+    return u
+
+
+def test_sharded_pixel_map_and_sweep(gpu_solver_cls):
+    ub, f = synth_batch(4, 40, 36, seed=33)
+    amap = 0.05 + 0.1 * np.random.default_rng(5).random((40, 36))
+    (u0, c0, g0), _ = _single(gpu_solver_cls, ub, f, amap, maxiter=300)
+    s = gpu_solver_cls(36, 40, 4, devices=[0, 0])
+    s.set_data(ub, f)
+    u, c, g = s.evaluate(amap, 0.1, maxiter=300)
+    assert np.array_equal(u, u0) and np.isclose(c, c0, rtol=1e-14)
+    assert g.shape == (40, 36) and np.allclose(g, g0, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    alphas = np.linspace(0.02, 0.2, 7)
+    costs, us = s.sweep(alphas, fetch_u=True, maxiter=200)
+    s1 = gpu_solver_cls(36, 40, 4)
+    s1.set_data(ub, f)
+    costs1, us1 = s1.sweep(alphas, fetch_u=True, maxiter=200)
+    s1.close()
+    assert np.array_equal(us, us1) and np.allclose(costs, costs1, rtol=1e-14)
+    # more shards than images: no empty shard is created
+    s2 = gpu_solver_cls(36, 40, 2, devices=[0, 0, 0, 0])
+    assert s2.stats()["shards"] == 2
+    s2.close()
+    # device-pointer entry points are ambiguous over several shards
+    from bpldenoising_amd._lib import BpltvError
+    with pytest.raises(BpltvError) as e:
+        s.u_device_ptr()
+    assert e.value.code == 6
+    s.close()
+
+
+def test_multi_handle_reports_shard_errors(gpu_solver_cls):
+    from bpldenoising_amd._lib import BpltvError
+    s = gpu_solver_cls(32, 32, 2, devices=[0, 0])
+    with pytest.raises(BpltvError) as e:
+        s.denoise(0.1, maxiter=5)                      # no data yet
+    assert e.value.code == 3 and "shard" in str(e.value)
+    with pytest.raises(BpltvError):
+        gpu_solver_cls(32, 32, 2, ngpus=99)            # more devices than visible
+    s.close()

@@ -167,6 +167,26 @@ def test_full_size_properties_1024(gpu_solver_cls):
     s.close()
 
 
+def test_full_size_matches_oracle_1024(gpu_solver_cls, oracle):
+    """BASELINE config 5 at full image size against the C oracle: 2 x 1024 x 1024, the spatially varying alpha
+    of SURVEY 8(d), 32 iterations (the oracle does this in well under a second on the host).  Bit-exact for
+    the automatic plan (48x48 regions, variant 13) and for the 64x64 / 4 px variant."""
+    O, N, M = 2, 1024, 1024
+    ub, f = synth_batch(O, N, M, seed=10)
+    jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+    amap = 0.11 + 0.09 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
+    u0 = oracle.pdhg(f, amap, maxiter=32, nthreads=8)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u_auto = s.denoise(amap, maxiter=32)
+    st = s.stats()
+    assert st["tiles"] == O * 32 * 32 and st["bytes_per_px_iter"] == 64.0     # 48x48 regions, T = 8
+    assert np.array_equal(u_auto, u0)
+    assert np.array_equal(s.denoise(amap, maxiter=32, variant=2), u0)
+    assert np.array_equal(s.denoise(0.1, maxiter=32), oracle.pdhg(f, 0.1, maxiter=32, nthreads=8))   # scalar alpha
+    s.close()
+
+
 def test_operators_match_oracle(gpu_solver_cls, oracle):
     rng = np.random.default_rng(11)
     N, M = 37, 29
