@@ -14,10 +14,17 @@ The scalar path reproduces the reference *as written*, quirks included:
   * the radius is shrunk a second time when `pred < 0` (:247-249); a step is accepted when ρ > 0 (:251);
   * the iteration stops when Δ < tol after an iteration, or after maxiter (BilevelVisualise.jl:190,246).
 The array path (L-BFGS model + CG, TRBox.jl:99-114,135-146) depends on LinearOperators.jl's
-`LBFGSOperator` and Krylov.jl's `cg_lanczos`, which are external and unpinned; `LBFGSOperator`
-below is an own implementation of the standard forward L-BFGS operator (memory 5, initial scaling
-y'y/y's) and is documented as such.  Note the reference calls `push!(B, y, s)` with (y, s) in that
-order (:176); the same order is kept here.
+`LBFGSOperator` and Krylov.jl's `cg_lanczos`, which are external and unpinned (`Project.toml` has no
+`[compat]` entry for either) -- PARITY UNPINNED for the array-alpha outer step.  What the text of the
+reference does fix is reproduced literally:
+  * `init_rest` builds `LBFGSOperator(length(x[:]))` with the package defaults (:50), restated here as
+    LinearOperators.jl's documented defaults: memory 5, `scaling = true` (initial matrix (y'y / y's) I from
+    the newest pair), no damping, a pair is stored only when y's > 1e-20 (the operator's own curvature test);
+  * `updateBFGS!(B, y, s)` pushes only when  y' (B y) > 0  (:174-179) -- the guard is on the CURRENT model
+    applied to y = gx_new - gx, not on y's -- and calls `push!(B, y[:], s[:])`, i.e. with y in the slot
+    LinearOperators.jl names `s` and s in the slot it names `y` (:176); the same order is kept here;
+  * `newton_step` solves B pn = -gx by conjugate gradients (`cg_lanczos`, :135-141; own CG below, exact in
+    <= n steps for the n <= 4 parameters of the shipped configs); `cauchy_step` is (:143-146) verbatim.
 """
 import numpy as np
 
@@ -56,6 +63,7 @@ class LBFGSOperator:
         self.S, self.Y = [], []
 
     def push(self, s, y):
+        """LinearOperators.jl `push!(op, s, y)`: store the pair when y's > 1e-20 (the operator's own test)."""
         s = np.asarray(s, dtype=np.float64).ravel(); y = np.asarray(y, dtype=np.float64).ravel()
         if float(y @ s) > 1e-20:
             self.S.append(s.copy()); self.Y.append(y.copy())
@@ -94,6 +102,14 @@ def _cg(B, rhs, tol=1e-8, maxit=None):         # stands in for Krylov.cg_lanczos
         p = r + (rs_new / rs) * p
         rs = rs_new
     return x
+
+
+def updateBFGS(B, y, s):
+    """/root/reference/src/TRBox.jl:174-179: `if y[:]'*(B*y[:]) > 0  push!(B, y[:], s[:])  end`."""
+    yv = np.asarray(y, dtype=np.float64).ravel()
+    if float(yv @ B.matvec(yv)) > 0:
+        B.push(yv, np.asarray(s, dtype=np.float64).ravel())     # (y, s) in the reference's order
+    return B
 
 
 def dogleg_box(x, gx, B, delta):
@@ -148,7 +164,7 @@ def bilevel_learn(ds, learning_function, xinit, delta0, maxiter=20, tol=1e-5, et
         with np.errstate(divide="ignore", invalid="ignore"):
             rho = (fx - fxb) / predf                                   # :230
         if not scalar:
-            B.push(np.asarray(gxb) - np.asarray(gx), p)                # updateBFGS!(B, y, s) -> push!(B, y, s), :176,237
+            updateBFGS(B, np.asarray(gxb) - np.asarray(gx), p)          # :237 -> :174-179
         if rho < eta1:                                                 # :239-245
             delta = beta1 * delta
         elif rho > eta2:

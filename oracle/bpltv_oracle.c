@@ -283,6 +283,101 @@ BPLO_API int bplo_pdhg(int M, int N, int O, const double *f, const double *alpha
     return fail ? 2 : 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The same ROF solver with each UNPINNED choice of the restatement flipped (tools/unpinned_study.py,
+ * tests/test_unpinned.py).  The loop of op_denoise_pdps lives in an absent package, so these are the degrees
+ * of freedom a faithful restatement has; the study bounds what they can change after the reference's 5000
+ * iterations.  Plain, unfused arithmetic (a*b+c written as such): these runs are compared with tolerances.
+ *   flags & 1   x0 = 0 instead of x0 = f
+ *   flags & 2   dual step first (y from xbar of the previous iteration, then x, then the over-relaxation)
+ *   flags & 4   projection by alpha / sqrt(n2) (IEEE sqrt and divide) instead of the Newton rsqrt
+ *   flags & 8   projection written as y / max(1, |y|/alpha)
+ *   flags & 16  step sizes updated BEFORE the over-relaxation uses omega (omega of the new tau)
+ *   L           operator-norm estimate dividing tau0 and sigma0 (restatement: sqrt(8))
+ * ---------------------------------------------------------------------------------------- */
+BPLO_API int bplo_pdhg_variant(int M, int N, int O, const double *f, const double *alpha, int am, int an,
+                               double tau0, double sigma0, int accel, int maxiter, int flags, double L,
+                               double *x_out, double *y1_out, double *y2_out, int nthreads)
+{
+    if (M < 1 || N < 1 || O < 0 || maxiter < 0 || !(L > 0.0)) return 1;
+    const size_t n = (size_t)M * N;
+    int fail = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int img = 0; img < O; ++img) {
+        const double *fk = f + n * img;
+        double *x = x_out + n * img;
+        double *xb = (double *)malloc(n * sizeof(double));
+        double *y1 = y1_out ? y1_out + n * img : (double *)malloc(n * sizeof(double));
+        double *y2 = y2_out ? y2_out + n * img : (double *)malloc(n * sizeof(double));
+        if (!xb || !y1 || !y2) { fail = 1; free(xb); if (!y1_out) free(y1); if (!y2_out) free(y2); continue; }
+        for (size_t k = 0; k < n; ++k) {
+            x[k] = (flags & 1) ? 0.0 : fk[k];
+            xb[k] = x[k];
+            y1[k] = 0.0;
+            y2[k] = 0.0;
+        }
+        double tau = tau0 / L, sigma = sigma0 / L;
+        const double gamma = 1.0;
+        for (int it = 0; it < maxiter; ++it) {
+            double omega = accel ? 1.0 / sqrt(1.0 + 2.0 * gamma * tau) : 1.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int do_dual = (flags & 2) ? (pass == 0) : (pass == 1);
+                if (!do_dual) {
+                    if ((flags & 16) && accel) {   /* new steps first: omega belongs to the updated tau */
+                        /* (tau, sigma) of THIS primal step stay; only omega changes */
+                        omega = 1.0 / sqrt(1.0 + 2.0 * gamma * (tau * omega));
+                    }
+                    for (int j = 0; j < N; ++j)
+                        for (int i = 0; i < M; ++i) {
+                            size_t k = i + (size_t)M * j;
+                            double y1m = (i > 0) ? y1[k - 1] : 0.0;
+                            double y2m = (j > 0) ? y2[k - M] : 0.0;
+                            double a1 = (i < M - 1) ? y1[k] : 0.0, a2 = (j < N - 1) ? y2[k] : 0.0;
+                            double div = (y1m - a1) + (y2m - a2);
+                            double xo = x[k];
+                            double xn = (xo - tau * (div - fk[k])) / (1.0 + tau);
+                            xb[k] = xn + omega * (xn - xo);
+                            x[k] = xn;
+                        }
+                } else {
+                    for (int j = 0; j < N; ++j)
+                        for (int i = 0; i < M; ++i) {
+                            size_t k = i + (size_t)M * j;
+                            double d1 = (i < M - 1) ? xb[k + 1] - xb[k] : 0.0;
+                            double d2 = (j < N - 1) ? xb[k + M] - xb[k] : 0.0;
+                            double a = alpha_at(alpha, am, an, M, N, i, j);
+                            double y1n = y1[k] + sigma * d1;
+                            double y2n = y2[k] + sigma * d2;
+                            double n2 = y1n * y1n + y2n * y2n;
+                            if (flags & 8) {
+                                double m = sqrt(n2) / a;
+                                if (m > 1.0) { y1n = y1n / m; y2n = y2n / m; }
+                            } else if (n2 > a * a) {
+                                double v = (flags & 4) ? a / sqrt(n2) : a * rsqrt_nr(n2);
+                                y1n = y1n * v;
+                                y2n = y2n * v;
+                            }
+                            y1[k] = y1n;
+                            y2[k] = y2n;
+                        }
+                }
+            }
+            if (accel) {
+                omega = 1.0 / sqrt(1.0 + 2.0 * gamma * tau);
+                tau = tau * omega;
+                sigma = sigma / omega;
+            }
+        }
+        free(xb);
+        if (!y1_out) free(y1);
+        if (!y2_out) free(y2);
+    }
+    return fail ? 2 : 0;
+}
+
 /* cost = 0.5*norm2^2(u - ubar) over all entries (TVLearningFunctionVec.jl:20).  Per-image sums
  * in pixel order, then summed in image order. */
 BPLO_API double bplo_cost(int M, int N, int O, const double *u, const double *ubar, double *per_image)

@@ -35,6 +35,9 @@ def lib():
         L.bplo_pdhg_rows.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
                                      C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_int, C.c_int]
         L.bplo_pdhg_rows.restype = C.c_int
+        L.bplo_pdhg_variant.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, C.c_int]
+        L.bplo_pdhg_variant.restype = C.c_int
         L.bplo_cost.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
         L.bplo_cost.restype = C.c_double
         L.bplo_gap.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
@@ -97,6 +100,27 @@ def pdhg(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True,
     if return_dual:
         return x, y1.reshape(f.shape), y2.reshape(f.shape)
     return x
+
+
+VARIANT_FLAGS = {"x0_zero": 1, "dual_first": 2, "ieee_sqrt_div": 4, "max_form": 8, "omega_of_new_tau": 16}
+
+
+def pdhg_variant(f, alpha, maxiter=5000, flags=0, L=None, tau0=5.0, sigma0=0.99 / 5, accel=True, nthreads=1,
+                 return_dual=False):
+    """The restated recurrence with unpinned choices flipped (bplo_pdhg_variant; flags: VARIANT_FLAGS).
+    flags = 0, L = sqrt(8) is the oracle's recurrence in unfused arithmetic."""
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3); y1 = np.empty_like(f3); y2 = np.empty_like(f3)
+    rc = lib().bplo_pdhg_variant(M, N, O, _p(f3), _p(a), am, an, tau0, sigma0, int(accel), maxiter, int(flags),
+                                 float(np.sqrt(8.0) if L is None else L), _p(x), _p(y1), _p(y2), nthreads)
+    if rc:
+        raise RuntimeError("bplo_pdhg_variant rc=%d" % rc)
+    if return_dual:
+        return x.reshape(f.shape), y1.reshape(f.shape), y2.reshape(f.shape)
+    return x.reshape(f.shape)
 
 
 _native = None

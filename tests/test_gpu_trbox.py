@@ -40,6 +40,24 @@ def test_patch_bilevel_cameraman(gpu_solver_cls, oracle):
     assert np.abs(ug - uo).max() < 1e-9
 
 
+def test_patch_bilevel_cameraman_full_budget(gpu_solver_cls, oracle):
+    """The reference's whole outer budget (maxiter = 20, tol = 1e-5, /root/reference/src/BPLDenoising.jl:308-312,
+    350-357) for the 2x2 patch parameter on cameraman_128_10 with the reference's 5000 inner iterations: the HIP-driven
+    and the oracle-driven loop take the same accept/reject decisions (same radius sequence) and learn the same
+    parameter.  The L-BFGS operator / CG of the harness are restatements of unpinned packages (trbox.py)."""
+    import bpldenoising_amd as B
+    ub, f = T.load_dataset(DATASETS_NPZ, "cameraman_128_10")
+    x0 = 1e-4 * np.ones((2, 2))
+    xg, ug, hg = trbox.bilevel_learn((ub, f), lambda x, ds, d, **kw: B.tv_op_learning_function(x, ds, d), x0, 1e-4,
+                                     maxiter=20, tol=1e-5)
+    xo, uo, ho = trbox.bilevel_learn((ub, f), _oracle_lf(oracle, 5000), x0, 1e-4, maxiter=20, tol=1e-5)
+    assert len(hg) == len(ho) == 20 or hg[-1]["radius_value"] < 1e-5
+    assert [h["radius_value"] for h in hg] == [h["radius_value"] for h in ho]
+    assert np.allclose(xg, xo, rtol=1e-5, atol=1e-12)
+    assert np.allclose([h["function_value"] for h in hg], [h["function_value"] for h in ho], rtol=1e-9)
+    assert np.abs(ug - uo).max() < 1e-8
+
+
 def test_scalar_driver_end_to_end(gpu_solver_cls, oracle, tmp_path):
     """`scalar_bilevel_tv_learn(dataset_name=..., num_samples=...)` with its default (HIP) learning function:
     the same learned parameter and log as when the driver is run on the oracle, and the artefacts exist."""

@@ -34,6 +34,19 @@ def test_lbfgs_operator_is_spd_and_secant():
     assert np.allclose(trbox._cg(B, A[:, 0]), np.linalg.solve(Bm, A[:, 0]), rtol=1e-6)
 
 
+def test_update_guard_is_the_references():
+    """TRBox.jl:174-179: the pair is pushed iff y'(B y) > 0 -- with B SPD that is any y != 0, including pairs
+    with y's < 0 that a y's test would drop before the operator's own curvature test sees them."""
+    B = trbox.LBFGSOperator(2)
+    y, s = np.array([1.0, 0.5]), np.array([0.2, 0.1])
+    trbox.updateBFGS(B, y, s)
+    assert len(B.S) == 1 and np.array_equal(B.S[0], y) and np.array_equal(B.Y[0], s)   # (y, s) order of :176
+    trbox.updateBFGS(B, np.zeros(2), s)                  # y'By = 0: not pushed
+    assert len(B.S) == 1
+    trbox.updateBFGS(B, np.array([1.0, 0.0]), np.array([-1.0, 0.0]))   # guard passes, the operator's y's > 1e-20 test drops it
+    assert len(B.S) == 1
+
+
 def oracle_lf(oracle, maxiter):
     def lf(x, ds, delta, **kw):
         return oracle.tv_op_learning_function(x, ds, delta, maxiter=maxiter, nthreads=4)

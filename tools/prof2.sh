@@ -1,0 +1,56 @@
+#!/bin/bash
+# Profile recipe of round 2 (run on the GPU box through gpurun; outputs under gpurun_out/prof2/).
+# Every rocprofv3 --pmc pass holds counters of ONE budget class that fits the hardware (MI355X_MICROARCH.md,
+# "rocprofv3 PMC slots": SQ 8 per pass; TCC 4, FETCH_SIZE costs 3 and WRITE_SIZE 2 -> separate passes), the
+# program comes directly after `--`, and no trace domain is combined with --pmc.
+# usage: tools/prof2.sh [part ...]   parts: bench cfg5 eval128 evalcfg5   (default: all)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof2
+mkdir -p $OUT
+cd $R
+export TMPDIR=/tmp
+PARTS=${@:-bench cfg5 eval128 evalcfg5}
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
+SQ2="SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
+kt()  { local tag=$1; shift; echo "== kernel trace $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
+pmc() { local tag=$1; local ctr=$2; shift 2; echo "== pmc $tag: $ctr"; rocprofv3 --pmc $ctr --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
+for part in $PARTS; do
+case $part in
+bench)
+  python3 bench.py --steps 10 --warmup 3 > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
+  tail -1 $OUT/bench.log | cut -c1-400
+  kt kt_bench python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph"
+  pmc pmc_bench_sq1 "$SQ1" $B
+  pmc pmc_bench_fetch "FETCH_SIZE" $B
+  pmc pmc_bench_write "WRITE_SIZE" $B
+  ;;
+cfg5)
+  C="python3 bench.py --images 8 --size 1024 --alpha-map --iters 400 --steps 2 --warmup 1 --no-cpu-baseline"
+  $C > $OUT/bench_cfg5.log 2>&1 || { tail -20 $OUT/bench_cfg5.log; exit 1; }
+  tail -1 $OUT/bench_cfg5.log | cut -c1-400
+  kt kt_cfg5 $C
+  pmc pmc_cfg5_sq1 "$SQ1" $C --no-graph
+  pmc pmc_cfg5_fetch "FETCH_SIZE" $C --no-graph
+  pmc pmc_cfg5_write "WRITE_SIZE" $C --no-graph
+  ;;
+eval128)
+  kt kt_eval128 python3 tools/eval_once.py
+  pmc pmc_eval128_sq1 "$SQ1" python3 tools/eval_once.py
+  pmc pmc_eval128_sq2 "$SQ2" python3 tools/eval_once.py
+  ;;
+evalcfg5)
+  python3 tools/eval_cfg5.py 8 3 400 > $OUT/eval_cfg5.log 2>&1 || { tail -20 $OUT/eval_cfg5.log; exit 1; }
+  cat $OUT/eval_cfg5.log
+  kt kt_evalcfg5 python3 tools/eval_cfg5.py 8 1 400
+  pmc pmc_evalcfg5_sq1 "$SQ1" python3 tools/eval_cfg5.py 8 1 400
+  pmc pmc_evalcfg5_sq2 "$SQ2" python3 tools/eval_cfg5.py 8 1 400
+  pmc pmc_evalcfg5_fetch "FETCH_SIZE" python3 tools/eval_cfg5.py 8 1 400
+  pmc pmc_evalcfg5_write "WRITE_SIZE" python3 tools/eval_cfg5.py 8 1 400
+  ;;
+esac
+done
+# keep only the summaries (the raw per-dispatch csv of a 40k-launch evaluate is ~100 MB; gpurun returns 64 MiB)
+python3 tools/refresh_profiles.py aggregate $OUT
+du -sh $OUT

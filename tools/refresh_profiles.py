@@ -1,52 +1,164 @@
 #!/usr/bin/env python3
-"""Copy the summaries of the last tools/prof1.sh run (gpurun_out/) into profiles/ (tracked)."""
-import csv, glob, json, os, shutil, collections
+"""profiles/ bookkeeping for tools/prof2.sh.
+
+  refresh_profiles.py aggregate <dir>    ON THE GPU BOX, after the rocprofv3 passes: reduce every raw
+        *counter_collection.csv to one row per (kernel, counter) -- dispatches, mean and sum per dispatch -- and
+        every *kernel_trace.csv to its *kernel_stats.csv, then delete the raw per-dispatch files (a 40k-launch
+        evaluate is ~100 MB of rows; gpurun brings back 64 MiB).
+  refresh_profiles.py publish [tag]      IN THE BUILD CONTAINER: copy the summaries of gpurun_out/prof2/ into
+        profiles/<tag>_*.csv and rebuild profiles/traffic.json (HBM bytes and VALU wave-instructions per
+        pdhg_tile_kernel launch, per workload) with the gfx950 FETCH_SIZE x2 correction of
+        /opt/skills/guides/MI355X_MICROARCH.md (section HBM).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out"); PRO = os.path.join(ROOT, "profiles")
+PRO = os.path.join(ROOT, "profiles")
+SRC = os.path.join(ROOT, "gpurun_out", "prof2")
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name).replace("bpltv::", "")
+
+
+def aggregate(d):
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        grid = {}
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = (short(r["Kernel_Name"]), r["Counter_Name"])
+                a = agg[k]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+                grid.setdefault(k[0], (r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), r.get("LDS_Block_Size", ""),
+                                       r.get("VGPR_Count", ""), r.get("SGPR_Count", "")))
+        out = os.path.join(os.path.dirname(path), "pmc_summary.csv")
+        with open(out, "w") as fh:
+            fh.write("kernel,counter,dispatches,mean_per_dispatch,sum,grid_size,workgroup_size,lds,vgpr,sgpr\n")
+            for (k, c), (n, s) in sorted(agg.items()):
+                g = grid[k]
+                fh.write('"%s",%s,%d,%.6g,%.6g,%s\n' % (k, c, n, s / n, s, ",".join(str(x) for x in g)))
+        os.remove(path)
+    for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        # per-kernel busy time and the gaps in front of it (what a --stats table does not show)
+        rows = []
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+        rows.sort()
+        agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        prev_end = None
+        for st, en, nm in rows:
+            a = agg[nm]
+            a[0] += 1
+            a[1] += (en - st) / 1e3
+            if prev_end is not None and st > prev_end:
+                a[2] += (st - prev_end) / 1e3
+            prev_end = max(prev_end, en) if prev_end else en
+        with open(os.path.join(os.path.dirname(path), "timeline_summary.csv"), "w") as fh:
+            fh.write("kernel,calls,busy_us,avg_us,idle_gap_before_us\n")
+            for nm, (c, b, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                fh.write('"%s",%d,%.1f,%.3f,%.1f\n' % (nm, c, b, b / c, g))
+            if rows:
+                fh.write('"(span of the trace)",%d,%.1f,,\n' % (len(rows), (max(r[1] for r in rows) - rows[0][0]) / 1e3))
+        os.remove(path)
+    for pat in ("*agent_info.csv", "*_domain_stats.csv"):
+        for path in glob.glob(os.path.join(d, "**", pat), recursive=True):
+            os.remove(path)
+
 
 def newest(pattern):
-    fs = glob.glob(os.path.join(OUT, pattern))
+    fs = glob.glob(os.path.join(SRC, pattern), recursive=True)
     return max(fs, key=os.path.getmtime) if fs else None
 
-def mean_counters(path, kernel_sub):
-    rows = list(csv.DictReader(open(path)))
-    agg = collections.defaultdict(list)
-    for r in rows:
-        if kernel_sub in r["Kernel_Name"]:
-            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    return {k: (len(v), sum(v) / len(v)) for k, v in agg.items()}
 
-tag = os.environ.get("PROFILE_TAG", "r01")
-ks = newest("prof_kt/*/*kernel_stats.csv")
-if ks:
-    shutil.copy(ks, os.path.join(PRO, "%s_kernel_stats_bench.csv" % tag))
-ev = newest("prof_eval/*/*kernel_stats.csv")
-if ev:
-    shutil.copy(ev, os.path.join(PRO, "%s_kernel_stats_evaluate_v4_bcr.csv" % tag))
-p1 = newest("prof_pmc1/*/*counter_collection.csv")
-if p1:
-    m = mean_counters(p1, "pdhg_tile_kernel")
-    with open(os.path.join(PRO, "%s_pmc_sq_pdhg_summary.csv" % tag), "w") as f:
-        f.write("kernel,counter,dispatches,mean_per_dispatch\n")
-        for (k, c), (n, v) in sorted(m.items()):
-            f.write('"%s",%s,%d,%.1f\n' % (k, c, n, v))
-p2, p3 = newest("prof_pmc2/*/*counter_collection.csv"), newest("prof_pmc3/*/*counter_collection.csv")
-if p2 and p3:
-    fe = [v for (k, c), v in mean_counters(p2, "pdhg_tile_kernel").items() if c == "FETCH_SIZE"][0][1]
-    wr = [v for (k, c), v in mean_counters(p3, "pdhg_tile_kernel").items() if c == "WRITE_SIZE"][0][1]
+def pmc_mean(tagdir, kernel_sub, counter):
+    p = newest(os.path.join(tagdir, "**", "pmc_summary.csv"))
+    if not p:
+        return None
+    best = None
+    for r in csv.DictReader(open(p)):
+        if kernel_sub in r["kernel"] and r["counter"] == counter:
+            if best is None or int(r["dispatches"]) > best[0]:
+                best = (int(r["dispatches"]), float(r["mean_per_dispatch"]))
+    return best[1] if best else None
+
+
+def publish(tag):
+    os.makedirs(PRO, exist_ok=True)
+    copied = []
+    for sub, name in (("kt_bench", "kernel_stats_bench"), ("kt_cfg5", "kernel_stats_cfg5_pdhg"),
+                      ("kt_eval128", "kernel_stats_evaluate_128"), ("kt_evalcfg5", "kernel_stats_cfg5_evaluate")):
+        ks = newest(os.path.join(sub, "**", "*kernel_stats.csv"))
+        if ks:
+            shutil.copy(ks, os.path.join(PRO, "%s_%s.csv" % (tag, name))); copied.append(name)
+        tl = newest(os.path.join(sub, "**", "timeline_summary.csv"))
+        if tl:
+            shutil.copy(tl, os.path.join(PRO, "%s_%s_timeline.csv" % (tag, name.replace("kernel_stats_", "")))); copied.append(name + "_timeline")
+    for sub, name in (("pmc_bench_sq1", "pmc_sq_pdhg"), ("pmc_cfg5_sq1", "pmc_sq_cfg5_pdhg"), ("pmc_eval128_sq1", "pmc_sq1_evaluate_128"),
+                      ("pmc_eval128_sq2", "pmc_sq2_evaluate_128"), ("pmc_evalcfg5_sq1", "pmc_sq1_cfg5_evaluate"),
+                      ("pmc_evalcfg5_sq2", "pmc_sq2_cfg5_evaluate"), ("pmc_evalcfg5_fetch", "pmc_fetch_cfg5_evaluate"),
+                      ("pmc_evalcfg5_write", "pmc_write_cfg5_evaluate"), ("pmc_bench_fetch", "pmc_fetch_pdhg"),
+                      ("pmc_bench_write", "pmc_write_pdhg"), ("pmc_cfg5_fetch", "pmc_fetch_cfg5_pdhg"),
+                      ("pmc_cfg5_write", "pmc_write_cfg5_pdhg")):
+        p = newest(os.path.join(sub, "**", "pmc_summary.csv"))
+        if p:
+            shutil.copy(p, os.path.join(PRO, "%s_%s_summary.csv" % (tag, name))); copied.append(name)
+    for log, name in (("bench.log", "bench_line"), ("bench_cfg5.log", "bench_line_cfg5")):
+        p = os.path.join(SRC, log)
+        if os.path.exists(p):
+            lines = [l for l in open(p) if l.startswith("{")]
+            if lines:
+                open(os.path.join(PRO, "%s_%s.json" % (tag, name)), "w").write(lines[-1]); copied.append(name)
+    p = os.path.join(SRC, "eval_cfg5.log")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(PRO, "%s_eval_cfg5.log" % tag)); copied.append("eval_cfg5.log")
+    # traffic.json: per workload, HBM-side bytes and VALU wave-instructions of one pdhg_tile_kernel launch
     tf = os.path.join(PRO, "traffic.json")
-    t = json.load(open(tf))
-    t["FETCH_SIZE_KiB_per_10_image_launch"] = fe
-    t["WRITE_SIZE_KiB_per_10_image_launch"] = wr
-    t["hbm_bytes_per_10_image_launch"] = t["hbm_bytes_per_launch"] = (2 * fe + wr) * 1024
-    json.dump(t, open(tf, "w"), indent=1)
-bl = os.path.join(OUT, "bench1.log")
-if os.path.exists(bl):
-    line = [l for l in open(bl) if l.startswith("{")][-1]
-    open(os.path.join(PRO, "%s_bench_line.json" % tag), "w").write(line)
-    b = json.loads(line)
-    print("bench:", b["value"], b["roofline"]["frac"], b["roofline"]["avg_launch_us"], b["cpu_baseline"])
-if ks:
-    for r in csv.DictReader(open(ks)):
-        if "pdhg_tile_kernel" in r["Name"]:
-            print("rocprof:", r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, "us")
+    tj = {"workloads": {}}
+    if os.path.exists(tf):
+        try:
+            old = json.load(open(tf))
+            if "workloads" in old:
+                tj = old
+        except Exception:
+            pass
+    tj["correction"] = ("gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, section HBM); "
+                        "WRITE_SIZE exact; both in KiB per dispatch")
+    for key, pre, line in (("10x128x128 scalar", "pmc_bench", "bench_line"), ("8x1024x1024 map", "pmc_cfg5", "bench_line_cfg5")):
+        fe = pmc_mean(pre + "_fetch", "pdhg_tile_kernel", "FETCH_SIZE")
+        wr = pmc_mean(pre + "_write", "pdhg_tile_kernel", "WRITE_SIZE")
+        vi = pmc_mean(pre + "_sq1", "pdhg_tile_kernel", "SQ_INSTS_VALU")
+        bl = os.path.join(PRO, "%s_%s.json" % (tag, line))
+        if fe is None or wr is None or not os.path.exists(bl):
+            continue
+        b = json.loads(open(bl).read())
+        tj["workloads"][key] = {
+            "round": tag, "tile_iters": b["config"]["tile_iters"], "tiles": b["config"]["tiles_per_launch"],
+            "FETCH_SIZE_KiB_per_launch": fe, "WRITE_SIZE_KiB_per_launch": wr,
+            "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
+            "valu_wave_instructions_per_launch": vi,
+            "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+            "source": "tools/prof2.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
+        }
+    json.dump(tj, open(tf, "w"), indent=1)
+    print("published:", ", ".join(copied))
+    print(json.dumps(tj["workloads"], indent=1))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "aggregate":
+        aggregate(sys.argv[2])
+    elif len(sys.argv) >= 2 and sys.argv[1] == "publish":
+        publish(sys.argv[2] if len(sys.argv) > 2 else "r02")
+    else:
+        print(__doc__)
