@@ -21,18 +21,110 @@
 
 namespace bpltv {
 
-// band <- assembled matrix (4 diagonals), zero elsewhere.  grid (nblocks, O), grid-stride over the
-// n*W entries of one image (a flat launch over all images would exceed 2^32 work-items at 8 x 1024^2).
-__global__ __launch_bounds__(256) void hb_init_kernel(const double* __restrict__ band4, int M, int N, int O,
+// The assembled matrix as a few diagonals of its lower band: plane t holds A[c + off[t]][c] at
+// planes[t * tot + img * n + c] (TV: offsets 0, 1, M-1, M = adj_assemble_kernel's band4; the sum-of-regularisers
+// model has seven).  Offsets may coincide for tiny M: coinciding planes add.
+struct BandDiags {
+    const double* planes;
+    size_t tot;   // doubles per plane (= O * n)
+    int nd;
+    int off[8];
+};
+__device__ __forceinline__ double band_entry(const BandDiags& D, size_t ib, int n, long c, int d) {
+    if (c < 0 || c + d >= n) return 0.0;
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < D.nd && d == D.off[t]) v += D.planes[(size_t)t * D.tot + ib + c];
+    return v;
+}
+
+// Twisted (two-sided) factorisation of the band: the column range splits into top [0, m), middle [m, m + nm)
+// and bottom [m + nm, n).  Problem (img, side) of `sides` per image is a banded matrix of np = m + bw rows whose
+// first m columns are eliminated: side 0 = the leading principal submatrix of A, side 1 = the trailing one with
+// its index reversed (local k' = global n-1-k'); both leave their Schur complement on the middle in their last
+// bw columns.  sides = 1: the whole matrix (np = n).
+// band[p][np][W] <- that problem's matrix, zero elsewhere.  grid (nblocks, O * sides), grid-stride over np * W
+// entries (a flat launch over all images would exceed 2^32 work-items at 8 x 1024^2).
+__global__ __launch_bounds__(256) void hb_init_kernel(BandDiags D, int bw, int n, int sides, int np,
                                                       double* __restrict__ band) {
-    const int W = M + 1;
-    const size_t n = (size_t)M * N, tot = n * O;
-    const size_t ib = (size_t)blockIdx.y * n;
-    const size_t cnt = n * W, stride = (size_t)gridDim.x * 256;
+    const int W = bw + 1;
+    const int p = blockIdx.y, img = p / sides, side = p - img * sides;
+    const size_t ib = (size_t)img * n;
+    double* Bp = band + (size_t)p * np * W;
+    const size_t cnt = (size_t)np * W, stride = (size_t)gridDim.x * 256;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += stride) {
-        const size_t col = e / W;
-        const int d = (int)(e - col * W);
-        band[ib * W + e] = band_init(band4, tot, ib + col, d, M);
+        const long col = (long)(e / W);
+        const int d = (int)(e - (size_t)col * W);
+        double v = 0.0;
+        if (col + d < np) v = (side == 0) ? band_entry(D, ib, n, col, d) : band_entry(D, ib, n, (long)n - 1 - col - d, d);
+        Bp[e] = v;
+    }
+}
+
+// Middle block of the twisted factorisation: S = A_mid - (A_mid - S_top) - (A_mid - S_bot) with the two side
+// problems' trailing windows.  mid[img][nm][W] (a banded problem of nm rows, bandwidth min(bw, nm-1)).
+__global__ __launch_bounds__(256) void hb_mid_gather_kernel(BandDiags D, int bw, int n, int m, int nm, int np,
+                                                            const double* __restrict__ side, double* __restrict__ mid) {
+    const int W = bw + 1;
+    const int img = blockIdx.y;
+    const size_t ib = (size_t)img * n;
+    const double* top = side + (size_t)(2 * img) * np * W;
+    const double* bot = side + (size_t)(2 * img + 1) * np * W;
+    double* Mi = mid + (size_t)img * nm * W;
+    const size_t cnt = (size_t)nm * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e / W), d = (int)(e - (size_t)c * W), r = c + d;
+        double v = 0.0;
+        if (r < nm) {
+            const double a = band_entry(D, ib, n, (long)m + c, d);
+            v = a;
+            if (r < bw) v -= a - top[(size_t)(m + c) * W + d];
+            if (c >= nm - bw) v -= a - bot[(size_t)(n - 1 - m - r) * W + d];
+        }
+        Mi[e] = v;
+    }
+}
+
+// Right-hand side / solution vectors of the twisted solve.  vs[p][np]: side problems, vm[img][nm]: middle.
+// mode 0: vs <- vec (top: vec[k'], bottom: vec[n-1-k']).
+// mode 1: vm <- middle right-hand side from the side vectors' windows after the forward sweeps:
+//         b_m - (b_m - vs_top[m + r]) - (b_m - vs_bot[n-1-m-r]) on their supports.
+// mode 2: side windows <- middle solution xm (rows m .. np-1 of xs), before the backward sweeps.
+// mode 3: vec <- solution (top xs | xm | bottom xs reversed); acc += solution when acc != nullptr.
+__global__ __launch_bounds__(256) void hb_tw_vec_kernel(int mode, int bw, int n, int m, int nm, int np,
+                                                        double* __restrict__ vec, double* __restrict__ vs,
+                                                        double* __restrict__ xs, double* __restrict__ vm,
+                                                        double* __restrict__ acc) {
+    const int img = blockIdx.y;
+    double* v = vec + (size_t)img * n;
+    double* st = vs + (size_t)(2 * img) * np;
+    double* sb = vs + (size_t)(2 * img + 1) * np;
+    double* xt = xs + (size_t)(2 * img) * np;
+    double* xb = xs + (size_t)(2 * img + 1) * np;
+    double* mm = vm + (size_t)img * nm;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (mode == 0) {
+        if (g < np) { st[g] = v[g]; sb[g] = v[n - 1 - g]; }
+    } else if (mode == 1) {
+        if (g < nm) {
+            const double b = v[m + g];
+            double r = b;
+            if (g < bw) r -= b - st[m + g];
+            if (g >= nm - bw) r -= b - sb[n - 1 - m - g];
+            mm[g] = r;
+        }
+    } else if (mode == 2) {
+        if (g < nm) {
+            if (g < bw) xt[m + g] = mm[g];
+            if (g >= nm - bw) xb[n - 1 - m - g] = mm[g];
+        }
+    } else {
+        if (g < n) {
+            const double x = (g < m) ? xt[g] : ((g < m + nm) ? mm[g - m] : xb[n - 1 - g]);
+            v[g] = x;
+            if (acc) acc[(size_t)img * n + g] += x;
+        }
     }
 }
 
@@ -40,13 +132,13 @@ constexpr int HB2_NB = 128;
 
 // grid (O), block BCR_PT, dynamic LDS bcr_potrf_lds(HB2_NB)
 // Linv, LinvT: [O][npanel][128 x 128], kept for the substitutions; L11: [O][128 x 128] (this panel only).
-__global__ __launch_bounds__(BCR_PT) void hb2_potrf_kernel(const double* __restrict__ band, int M, int N, int k0,
+__global__ __launch_bounds__(BCR_PT) void hb2_potrf_kernel(const double* __restrict__ band, int bw, int n, int k0,
                                                            int npanel, double* __restrict__ Linv,
                                                            double* __restrict__ LinvT, double* __restrict__ L11,
                                                            int* __restrict__ fail) {
     extern __shared__ double S[];
     constexpr int MP = HB2_NB, ld = MP + 1;
-    const int W = M + 1, bw = M, n = M * N;
+    const int W = bw + 1;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const double* Bi = band + (size_t)img * n * W + (size_t)k0 * W;   // A(k0+r, k0+c) = Bi[r + (W-1) c], r >= c
     for (int e0 = tid; e0 < MP * MP; e0 += 8 * BCR_PT) {   // batches of 8 independent loads (clamped addresses)
@@ -119,11 +211,11 @@ __device__ __forceinline__ void hb2_mma_chunk(const double* __restrict__ As, con
 }
 
 // P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2, O), block BG_T.
-__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void hb2_trsm_kernel(const double* __restrict__ band, int M, int N, int k0,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void hb2_trsm_kernel(const double* __restrict__ band, int bw, int n, int k0,
                                                         int npanel, const double* __restrict__ Linv,
                                                         double* __restrict__ P, int bwp) {
     __shared__ double lds[BG_LDS];
-    const int W = M + 1, bw = M, n = M * N;
+    const int W = bw + 1;
     const int img = blockIdx.y, tid = threadIdx.x;
     const int rt = blockIdx.x >> 1, c0 = (blockIdx.x & 1) * 64;
     const int R0 = k0 + HB2_NB + 64 * rt;
@@ -165,11 +257,11 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
 // copies L11.  grid (nt (nt+1) / 2, O), nt = ceil(bw/64); block BG_T.
 // tile0: index of the first tile of this launch (0: the three tiles of the next panel's diagonal block and
 // the L11 copy -- the next hb2_potrf_kernel only needs these; 3: the rest, which runs beside it).
-__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int M, int N, int k0,
+__global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int bw, int n, int k0,
                                                           const double* __restrict__ L11, const double* __restrict__ P,
                                                           int bwp, int tile0) {
     __shared__ double lds[BG_LDS];
-    const int W = M + 1, bw = M, n = M * N;
+    const int W = bw + 1;
     const int img = blockIdx.y, tid = threadIdx.x;
     double* Bi = band + (size_t)img * n * W;
     const double* Pi = P + (size_t)img * bwp * HB2_NB;
@@ -267,11 +359,11 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 // Backward (L^T x = y): in/out `y` = running right-hand side, solution rows -> `x` (and += acc).
 // grid (1 + ceil(bw/128), O), block BS_T.
 __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict__ band, const double* __restrict__ Linv,
-                                                       int M, int N, int k0, int npanel, double* __restrict__ x,
+                                                       int bw, int n, int k0, int npanel, double* __restrict__ x,
                                                        double* __restrict__ y) {
     __shared__ double v[HB2_NB], yb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
-    const int W = M + 1, bw = M, n = M * N;
+    const int W = bw + 1;
     const int img = blockIdx.y, tid = threadIdx.x;
     const double* Bi = band + (size_t)img * n * W;
     double* xv = x + (size_t)img * n;
@@ -312,28 +404,35 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
     }
 }
 
+// apply_only (twisted solve): block k0 lies in the trailing window of a partially factored problem; its
+// solution is already in `x` (the middle block's), only the earlier equations are updated.
 __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict__ band, const double* __restrict__ LinvT,
-                                                       int M, int N, int k0, int npanel, double* __restrict__ y,
-                                                       double* __restrict__ x, double* __restrict__ acc) {
+                                                       int bw, int n, int k0, int npanel, double* __restrict__ y,
+                                                       double* __restrict__ x, double* __restrict__ acc, int apply_only) {
     __shared__ double v[HB2_NB], xb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
-    const int W = M + 1, bw = M, n = M * N;
+    const int W = bw + 1;
     const int img = blockIdx.y, tid = threadIdx.x;
     const double* Bi = band + (size_t)img * n * W;
     double* yv = y + (size_t)img * n;
-    if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? yv[k0 + tid] : 0.0;
-    __syncthreads();
-    double s0 = 0.0, s1 = 0.0;
-    bcr_mv_partial(LinvT + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, 2, s0, s1);
-    const double val = bcr_mv_reduce(red, HB2_NB, s0, s1);
-    if (blockIdx.x == 0) {
-        if (tid < HB2_NB && k0 + tid < n) {
-            x[(size_t)img * n + k0 + tid] = val;
-            if (acc) acc[(size_t)img * n + k0 + tid] += val;
+    if (apply_only) {
+        if (blockIdx.x == 0) return;
+        if (tid < HB2_NB) xb[tid] = (k0 + tid < n) ? x[(size_t)img * n + k0 + tid] : 0.0;
+    } else {
+        if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? yv[k0 + tid] : 0.0;
+        __syncthreads();
+        double s0 = 0.0, s1 = 0.0;
+        bcr_mv_partial(LinvT + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, 2, s0, s1);
+        const double val = bcr_mv_reduce(red, HB2_NB, s0, s1);
+        if (blockIdx.x == 0) {
+            if (tid < HB2_NB && k0 + tid < n) {
+                x[(size_t)img * n + k0 + tid] = val;
+                if (acc) acc[(size_t)img * n + k0 + tid] += val;
+            }
+            return;
         }
-        return;
+        if (tid < HB2_NB) xb[tid] = (k0 + tid < n) ? val : 0.0;
     }
-    if (tid < HB2_NB) xb[tid] = (k0 + tid < n) ? val : 0.0;
     __syncthreads();
     // earlier equation k: y_k -= sum_c L[k0+c][k] x_{k0+c},  L[k0+c][k] = band[k*W + (k0 + c - k)]
     const int rr = tid & 127, part = tid >> 7;
@@ -343,8 +442,8 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
         const double* col = Bi + (size_t)k * W + (k0 - k);
         double a0 = 0.0, a1 = 0.0;
         const int cb = 16 * part;
-        if ((M & 1) == 0 && k0 - k + cb + 15 <= bw && k0 + cb + 15 < n) {
-            // the thread's 16 entries are one 128-byte line: eight 16-byte loads (k(W-1) + k0 is even for even M)
+        if ((bw & 1) == 0 && (((size_t)img * n) & 1) == 0 && k0 - k + cb + 15 <= bw && k0 + cb + 15 < n) {
+            // the thread's 16 entries are one 128-byte line: eight 16-byte loads (k(W-1) + k0 is even for even bw)
             double2 l[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) l[i] = *reinterpret_cast<const double2*>(col + cb + 2 * i);

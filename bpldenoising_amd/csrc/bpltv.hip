@@ -17,6 +17,7 @@
 
 #include "../../include/bpltv.h"
 #include "adjoint_hbm_kernels.hpp"
+#include "hb_band_solver.hpp"
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
@@ -94,8 +95,6 @@ struct bpltv_handle {
     int M = 0, N = 0, O = 0, device = 0, ncu = 0;
     size_t npx = 0, tot = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;             // wide-image adjoint: trailing update beside the next panel's Cholesky
-    hipEvent_t ev_hb[2] = {nullptr, nullptr};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_data = false;
     // dataset + state
@@ -136,9 +135,8 @@ struct bpltv_handle {
     double *d_invF = nullptr, *d_invB = nullptr;  // inverted 64x64 diagonal blocks of L, two layouts (x2 sides)
     double *d_L1 = nullptr, *d_dump = nullptr, *d_Lm = nullptr, *d_spill = nullptr;  // twisted factorisation
     bool adj_twisted = false;
-    bool adj_hbm = false;  // M too wide for the LDS window: band factored in place in HBM
-    double* d_band = nullptr;
-    double* d_hb2 = nullptr;   // 128-column panels: Linv11 | L11 | P per image
+    bool adj_hbm = false;  // M too wide for the LDS window: band factored in place in HBM (hb_band_solver.hpp)
+    HbBandSolver hb;
     double *d_p = nullptr, *d_r = nullptr, *d_gpix = nullptr;
     double* d_resn = nullptr;
     int* d_fail = nullptr;
@@ -631,20 +629,12 @@ int band_alloc(bpltv_t* h) {
     if (h->adj_hbm) {
         size_t freeb = 0, totalb = 0;
         (void)hipMemGetInfo(&freeb, &totalb);
-        const size_t np_ = (h->npx + HB2_NB - 1) / HB2_NB;
-        const size_t need = (tot * W + (size_t)h->O * 2 * np_ * HB2_NB * HB2_NB) * sizeof(double);
+        const size_t need = h->hb.bytes_needed(h->M, (int)h->npx, h->O);
         if (need + (2ull << 30) > freeb)
             return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free)",
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
-        HIPCHK(h, hipMalloc((void**)&h->d_band, tot * W * sizeof(double)));
-        // 128-column panels: L11^-1 and L11^-T of every panel (for the substitutions) | L11 (two buffers: the
-        // copy into the band runs beside the next panel's Cholesky) | P per image
-        const size_t bwp = (size_t)(h->M + 63) / 64 * 64, npanel = (h->npx + HB2_NB - 1) / HB2_NB;
-        HIPCHK(h, hipMalloc((void**)&h->d_hb2, (size_t)h->O * ((2 * npanel + 2) * HB2_NB * HB2_NB + bwp * HB2_NB) * sizeof(double)));
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(HB2_NB)));
-        HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-        for (auto& e : h->ev_hb) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const int rc = h->hb.alloc(h->M, (int)h->npx, h->O, h->stream);
+        if (rc) return set_err(h, rc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
     }
     if (!h->adj_hbm) {
         HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
@@ -702,70 +692,19 @@ int adj_choose(bpltv_t* h, const bpltv_params& p, AdjMethod* out) {
     return BPLTV_OK;
 }
 
-// Side buffers of the HBM band path, carved out of d_hb2.
-struct HbBuffers {
-    int npanel;
-    double *Linv, *LinvT, *L11, *P;
-    explicit HbBuffers(const bpltv_t* h) {
-        npanel = (int)((h->npx + HB2_NB - 1) / HB2_NB);
-        const size_t blk = (size_t)h->O * HB2_NB * HB2_NB;
-        Linv = h->d_hb2;
-        LinvT = Linv ? Linv + blk * npanel : nullptr;
-        L11 = Linv ? LinvT + blk * npanel : nullptr;     // two buffers (panel parity)
-        P = Linv ? L11 + 2 * blk : nullptr;
-    }
-};
-
-// Banded Cholesky in HBM (M > 138): panels of 128 columns, see adjoint_hbm_kernels.hpp.
+// Banded Cholesky in HBM (M > 138): hb_band_solver.hpp / adjoint_hbm_kernels.hpp; the matrix is handed over as
+// the four diagonals of adj_assemble_kernel.
 int factor_band_hbm(bpltv_t* h) {
-    const int M = h->M, N = h->N, O = h->O, n = (int)h->npx;
-    const HbBuffers hb(h);
-    const size_t nel = h->npx * ((size_t)M + 1);  // per image
-    const unsigned ib_blocks = (unsigned)std::min<size_t>((nel + 255) / 256, 65536);
-    hipLaunchKernelGGL(hb_init_kernel, dim3(ib_blocks, O), dim3(256), 0, h->stream, h->d_band4, M, N, O, h->d_band);
-    const int nt = (M + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
-    bool rest_pending = false;
-    for (int k0 = 0; k0 < n; k0 += HB2_NB) {
-        double* L11p = hb.L11 + (size_t)((k0 / HB2_NB) & 1) * O * HB2_NB * HB2_NB;
-        hipLaunchKernelGGL(hb2_potrf_kernel, dim3(O), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), h->stream, h->d_band, M, N, k0,
-                           hb.npanel, hb.Linv, hb.LinvT, L11p, h->d_fail);
-        if (rest_pending) {   // the previous panel's trailing update must be complete from here on
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
-            rest_pending = false;
-        }
-        if (k0 + HB2_NB < n)
-            hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, hb.npanel,
-                               hb.Linv, hb.P, bwp);
-        // look-ahead: the three tiles of the next diagonal block first; the rest of the trailing update
-        // runs on a second stream beside the next panel's (latency-bound, O-workgroup) Cholesky
-        hipLaunchKernelGGL(hb2_update_kernel, dim3(3, O), dim3(BG_T), 0, h->stream, h->d_band, M, N, k0, L11p, hb.P, bwp, 0);
-        if (ntile > 3) {
-            HIPCHK(h, hipEventRecord(h->ev_hb[0], h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_hb[0], 0));
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, O), dim3(BG_T), 0, h->stream2, h->d_band, M, N, k0, L11p, hb.P,
-                               bwp, 3);
-            HIPCHK(h, hipEventRecord(h->ev_hb[1], h->stream2));
-            rest_pending = true;
-        }
-    }
-    if (rest_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_hb[1], 0));
-    HIPCHK(h, hipGetLastError());
+    BandDiags D;
+    D.planes = h->d_band4; D.tot = h->tot; D.nd = 4;
+    D.off[0] = 0; D.off[1] = 1; D.off[2] = h->M - 1; D.off[3] = h->M;
+    const int rc = h->hb.factor(D, h->d_fail);
+    if (rc) return set_err(h, rc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
     return BPLTV_OK;
 }
 
-// vec <- A^-1 vec, accv += solution: one launch per 128-column block and direction; d_gpix is free during
-// the solves and holds y.
-void solve_band_hbm(bpltv_t* h, double* vec, double* accv) {
-    const int M = h->M, N = h->N, O = h->O, n = (int)h->npx;
-    const HbBuffers hb(h);
-    const unsigned chunks = 1 + (unsigned)((M + HB2_NB - 1) / HB2_NB);
-    for (int k0 = 0; k0 < n; k0 += HB2_NB)
-        hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb.Linv, M, N, k0, hb.npanel,
-                           vec, h->d_gpix);
-    for (int k0 = ((n - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
-        hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, O), dim3(BS_T), 0, h->stream, h->d_band, hb.LinvT, M, N, k0, hb.npanel,
-                           h->d_gpix, vec, accv);
-}
+// vec <- A^-1 vec, accv += solution; d_gpix is free during the solves and holds y.
+void solve_band_hbm(bpltv_t* h, double* vec, double* accv) { h->hb.solve(vec, accv, h->d_gpix); }
 
 // Banded Cholesky with the trailing window in LDS (M <= 138), twisted when the shape allows.
 struct LdsBandPlan {
@@ -1412,7 +1351,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
-                    h->d_band4, h->d_bcr, h->d_hb2, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_band, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
+                    h->d_band4, h->d_bcr, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int s = 0; s < 2; ++s)
@@ -1423,9 +1362,7 @@ int bpltv_destroy(bpltv_t* h) {
     if (h->d_sweep_cost) (void)hipFree(h->d_sweep_cost);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
-    for (auto e : h->ev_hb)
-        if (e) (void)hipEventDestroy(e);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    h->hb.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return BPLTV_OK;

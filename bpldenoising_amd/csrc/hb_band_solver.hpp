@@ -1,0 +1,238 @@
+// hb_band_solver.hpp -- host side of the HBM-resident banded Cholesky (kernels: adjoint_hbm_kernels.hpp).
+//
+// One object = workspace + launch sequences for O symmetric positive definite band matrices of order n and
+// bandwidth bw given as a few diagonals (BandDiags): the reduced adjoint systems of the TV model for images wider
+// than the LDS window (bw = M) and of the sum-of-regularisers model (bw = 2M: the centred stencil couples columns
+// j and j + 2).  Replaces the sparse LU behind Julia's `\` at /root/reference/src/TVLearningFunctionVec.jl:131,248
+// and /root/reference/src/SumRegsLearningFunction.jl:164,250,324,394.
+//
+// Twisted (two-sided) factorisation: the dependent chain of a banded Cholesky is one 128-column panel after the
+// other (diagonal block -> triangular solve -> first update tiles -> next diagonal block, ~80-115 us each on
+// MI355X however many CUs are idle), 8192 panels for a 1024 x 1024 image.  Eliminating from both ends at once
+// -- top columns in natural order, bottom columns in reversed order, as 2 O independent problems in the same
+// launches -- halves that depth for the factorisation and for every substitution at no extra arithmetic; the
+// two Schur complements meet in a dense middle block of ~bw columns that is factored last by the same kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "adjoint_hbm_kernels.hpp"
+
+namespace bpltv {
+
+__global__ void hb_fail_merge_kernel(const int* __restrict__ side, const int* __restrict__ mid, int sides, int O,
+                                     int* __restrict__ out) {
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= O) return;
+    int f = 0;
+    for (int s = 0; s < sides; ++s)
+        if (f == 0 && side[img * sides + s] != 0) f = side[img * sides + s];
+    if (f == 0 && mid && mid[img] != 0) f = mid[img];
+    if (f != 0 && out[img] == 0) out[img] = f;
+}
+
+struct HbBandSolver {
+    // shape
+    int bw = 0, n = 0, O = 0;
+    bool twisted = false;
+    int sides = 1;        // problems per image in the side array
+    int m = 0, nm = 0;    // twisted: eliminated columns per side, middle columns
+    int np = 0;           // rows of a side problem (m + bw; n when not twisted)
+    // device memory
+    double* band = nullptr;      // [O*sides][np][bw+1]
+    double* mid = nullptr;       // [O][nm][bw+1]
+    double* buf = nullptr;       // side problems: Linv | LinvT | L11 x2 | P
+    double* bufm = nullptr;      // middle problems
+    double* vec = nullptr;       // twisted solve: vs | ys | xs ([O*2][np] each) | vm | ym | xm ([O][nm] each)
+    int* fail = nullptr;         // [O*sides + O]
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool single_stream = false;  // profiling aid (BPLTV_HB_SINGLE_STREAM=1): rocprofv3 --pmc cannot follow two streams
+    std::string err;
+
+    struct Bufs {
+        int npanel;
+        double *Linv, *LinvT, *L11, *P;
+    };
+    static size_t bufs_doubles(int nprob, int ncol, int bw) {
+        const size_t npanel = (size_t)(ncol + HB2_NB - 1) / HB2_NB, bwp = (size_t)(bw + 63) / 64 * 64;
+        return (size_t)nprob * ((2 * npanel + 2) * HB2_NB * HB2_NB + bwp * HB2_NB);
+    }
+    static Bufs carve(double* base, int nprob, int ncol) {
+        Bufs b;
+        b.npanel = (ncol + HB2_NB - 1) / HB2_NB;
+        const size_t blk = (size_t)nprob * HB2_NB * HB2_NB;
+        b.Linv = base;
+        b.LinvT = base + blk * b.npanel;
+        b.L11 = b.LinvT + blk * b.npanel;   // two buffers (panel parity)
+        b.P = b.L11 + 2 * blk;
+        return b;
+    }
+
+    size_t bytes_needed(int bw_, int n_, int O_) const {
+        Shape s = shape(bw_, n_);
+        const size_t W = (size_t)bw_ + 1;
+        size_t d = (size_t)O_ * s.sides * s.np * W + bufs_doubles(O_ * s.sides, s.sides == 2 ? s.m : n_, bw_);
+        if (s.sides == 2) d += (size_t)O_ * s.nm * W + bufs_doubles(O_, s.nm, bw_) + (size_t)O_ * (6 * (size_t)s.np + 3 * (size_t)s.nm);
+        return d * sizeof(double);
+    }
+
+    struct Shape { int sides, m, nm, np; };
+    static Shape shape(int bw_, int n_) {
+        Shape s;
+        const long half = ((long)n_ - bw_) / 2;
+        s.m = (int)(half > 0 ? (half / HB2_NB) * HB2_NB : 0);
+        // worth it from a few panels per side; the middle must hold both trailing windows: nm >= bw
+        if (s.m >= 4 * HB2_NB) {
+            s.sides = 2;
+            s.nm = n_ - 2 * s.m;
+            s.np = s.m + bw_;
+        } else {
+            s.sides = 1; s.m = 0; s.nm = 0; s.np = n_;
+        }
+        return s;
+    }
+
+#define HBCHK(call)                                                                               \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            err = std::string(#call) + " failed: " + hipGetErrorString(e_);                       \
+            return e_ == hipErrorOutOfMemory ? 5 : 2;                                             \
+        }                                                                                         \
+    } while (0)
+
+    // returns 0, 2 (HIP error) or 5 (out of memory); `err` holds the message
+    int alloc(int bw_, int n_, int O_, hipStream_t st, bool allow_twist = true) {
+        bw = bw_; n = n_; O = O_; stream = st;
+        Shape s = allow_twist ? shape(bw, n) : Shape{1, 0, 0, n_};
+        twisted = s.sides == 2; sides = s.sides; m = s.m; nm = s.nm; np = s.np;
+        const size_t W = (size_t)bw + 1;
+        const char* e1 = getenv("BPLTV_HB_SINGLE_STREAM");
+        single_stream = e1 && e1[0] == '1';
+        HBCHK(hipMalloc((void**)&band, (size_t)O * sides * np * W * sizeof(double)));
+        HBCHK(hipMalloc((void**)&buf, bufs_doubles(O * sides, twisted ? m : n, bw) * sizeof(double)));
+        HBCHK(hipMalloc((void**)&fail, (size_t)O * 3 * sizeof(int)));
+        if (twisted) {
+            HBCHK(hipMalloc((void**)&mid, (size_t)O * nm * W * sizeof(double)));
+            HBCHK(hipMalloc((void**)&bufm, bufs_doubles(O, nm, bw) * sizeof(double)));
+            HBCHK(hipMalloc((void**)&vec, (size_t)O * (6 * (size_t)np + 3 * (size_t)nm) * sizeof(double)));
+        }
+        HBCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bcr_potrf_lds(HB2_NB)));
+        HBCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        for (auto& e : ev) HBCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return 0;
+    }
+
+    void release() {
+        for (void* p : {(void*)band, (void*)mid, (void*)buf, (void*)bufm, (void*)vec, (void*)fail})
+            if (p) (void)hipFree(p);
+        band = mid = buf = bufm = vec = nullptr; fail = nullptr;
+        for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (stream2) (void)hipStreamDestroy(stream2);
+        stream2 = nullptr;
+    }
+
+    // Right-looking blocked Cholesky of `nprob` band problems of `nrow` rows, eliminating columns [0, nelim):
+    // per panel of 128 columns potrf -> trsm -> first three update tiles (the next diagonal block), the rest of
+    // the trailing update on a second stream beside the next panel's (latency-bound, nprob-workgroup) potrf.
+    int factor_problems(double* B, int nprob, int nrow, int nelim, const Bufs& hb, int* d_fail) {
+        const int nt = (bw + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
+        bool rest_pending = false;
+        hipStream_t s2 = single_stream ? stream : stream2;
+        for (int k0 = 0; k0 < nelim; k0 += HB2_NB) {
+            double* L11p = hb.L11 + (size_t)((k0 / HB2_NB) & 1) * nprob * HB2_NB * HB2_NB;
+            hipLaunchKernelGGL(hb2_potrf_kernel, dim3(nprob), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, B, bw, nrow, k0,
+                               hb.npanel, hb.Linv, hb.LinvT, L11p, d_fail);
+            if (rest_pending && !single_stream) {   // the previous panel's trailing update must be complete from here on
+                HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+            }
+            rest_pending = false;
+            if (k0 + HB2_NB < nrow)
+                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, hb.npanel, hb.Linv,
+                                   hb.P, bwp);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(std::min(3, ntile), nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, hb.P,
+                               bwp, 0);
+            if (ntile > 3) {
+                if (!single_stream) {
+                    HBCHK(hipEventRecord(ev[0], stream));
+                    HBCHK(hipStreamWaitEvent(s2, ev[0], 0));
+                }
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, hb.P, bwp, 3);
+                if (!single_stream) HBCHK(hipEventRecord(ev[1], s2));
+                rest_pending = true;
+            }
+        }
+        if (rest_pending && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+        HBCHK(hipGetLastError());
+        return 0;
+    }
+
+    // band <- A (diagonals D), factor; d_fail_out[img] receives 1 + the first failing column (0: none).
+    int factor(const BandDiags& D, int* d_fail_out) {
+        const size_t W = (size_t)bw + 1;
+        HBCHK(hipMemsetAsync(fail, 0, (size_t)O * 3 * sizeof(int), stream));
+        const unsigned ib = (unsigned)std::min<size_t>(((size_t)np * W + 255) / 256, 65536);
+        hipLaunchKernelGGL(hb_init_kernel, dim3(ib, O * sides), dim3(256), 0, stream, D, bw, n, sides, np, band);
+        const Bufs hb = carve(buf, O * sides, twisted ? m : n);
+        int rc = factor_problems(band, O * sides, np, twisted ? m : n, hb, fail);
+        if (rc) return rc;
+        if (twisted) {
+            const unsigned mb = (unsigned)std::min<size_t>(((size_t)nm * W + 255) / 256, 65536);
+            hipLaunchKernelGGL(hb_mid_gather_kernel, dim3(mb, O), dim3(256), 0, stream, D, bw, n, m, nm, np, band, mid);
+            const Bufs hm = carve(bufm, O, nm);
+            rc = factor_problems(mid, O, nm, nm, hm, fail + 2 * O);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(hb_fail_merge_kernel, dim3((O + 63) / 64), dim3(64), 0, stream, fail, twisted ? fail + 2 * O : nullptr, sides,
+                           O, d_fail_out);
+        HBCHK(hipGetLastError());
+        return 0;
+    }
+
+    // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim)
+    void fwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* x, double* y) {
+        const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
+        for (int k0 = 0; k0 < nelim; k0 += HB2_NB)
+            hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.Linv, bw, nrow, k0, hb.npanel, x, y);
+    }
+    void bwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* y, double* x, double* acc) {
+        const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
+        // rows of the trailing window (partial factorisation): their solution is given, push it to the earlier rows
+        for (int k0 = ((nrow - 1) / HB2_NB) * HB2_NB; k0 >= nelim; k0 -= HB2_NB)
+            hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x,
+                               (double*)nullptr, 1);
+        for (int k0 = ((nelim - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
+            hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x, acc,
+                               0);
+    }
+
+    // v <- A^-1 v, accv += solution (accv may be null).  scratch: [O][n] doubles (not twisted: holds y).
+    void solve(double* v, double* accv, double* scratch) {
+        if (!twisted) {
+            const Bufs hb = carve(buf, O, n);
+            fwd(band, hb, O, n, n, v, scratch);
+            bwd(band, hb, O, n, n, scratch, v, accv);
+            return;
+        }
+        const Bufs hb = carve(buf, 2 * O, m), hm = carve(bufm, O, nm);
+        const size_t sv = (size_t)2 * O * np, sm = (size_t)O * nm;
+        double *vs = vec, *ys = vec + sv, *xs = vec + 2 * sv, *vm = vec + 3 * sv, *ym = vm + sm, *xm = vm + 2 * sm;
+        const unsigned gn = (unsigned)((n + 255) / 256), gp = (unsigned)((np + 255) / 256), gm = (unsigned)((nm + 255) / 256);
+        hipLaunchKernelGGL(hb_tw_vec_kernel, dim3(gp, O), dim3(256), 0, stream, 0, bw, n, m, nm, np, v, vs, xs, vm, (double*)nullptr);
+        fwd(band, hb, 2 * O, np, m, vs, ys);
+        hipLaunchKernelGGL(hb_tw_vec_kernel, dim3(gm, O), dim3(256), 0, stream, 1, bw, n, m, nm, np, v, vs, xs, vm, (double*)nullptr);
+        fwd(mid, hm, O, nm, nm, vm, ym);
+        bwd(mid, hm, O, nm, nm, ym, xm, nullptr);
+        hipLaunchKernelGGL(hb_tw_vec_kernel, dim3(gm, O), dim3(256), 0, stream, 2, bw, n, m, nm, np, v, vs, xs, xm, (double*)nullptr);
+        bwd(band, hb, 2 * O, np, m, ys, xs, nullptr);
+        hipLaunchKernelGGL(hb_tw_vec_kernel, dim3(gn, O), dim3(256), 0, stream, 3, bw, n, m, nm, np, v, vs, xs, xm, accv);
+    }
+#undef HBCHK
+};
+
+}  // namespace bpltv
