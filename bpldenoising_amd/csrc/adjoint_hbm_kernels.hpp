@@ -210,14 +210,15 @@ __device__ __forceinline__ void hb2_mma_chunk(const double* __restrict__ As, con
     }
 }
 
-// P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2, O), block BG_T.
+// P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2 * nprob), id = tile * nprob + problem; block BG_T.
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void hb2_trsm_kernel(const double* __restrict__ band, int bw, int n, int k0,
                                                         int npanel, const double* __restrict__ Linv,
-                                                        double* __restrict__ P, int bwp) {
+                                                        double* __restrict__ P, int bwp, int nprob) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
-    const int img = blockIdx.y, tid = threadIdx.x;
-    const int rt = blockIdx.x >> 1, c0 = (blockIdx.x & 1) * 64;
+    const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
+    const int bxt = (int)(blockIdx.x / (unsigned)nprob);
+    const int rt = bxt >> 1, c0 = (bxt & 1) * 64;
     const int R0 = k0 + HB2_NB + 64 * rt;
     if (R0 >= n) return;
     const double* Bi = band + (size_t)img * n * W;
@@ -253,61 +254,98 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
 }
 
 // Trailing update A(R, C) -= sum_k P(R, k) P(C, k) on the lower 64x64 tiles (ta >= tb) of the bw x bw block
-// behind the panel; the diagonal tiles also copy their 64 rows of P (= L21) into the band and tile 0
-// copies L11.  grid (nt (nt+1) / 2, O), nt = ceil(bw/64); block BG_T.
-// tile0: index of the first tile of this launch (0: the three tiles of the next panel's diagonal block and
-// the L11 copy -- the next hb2_potrf_kernel only needs these; 3: the rest, which runs beside it).
+// behind the panel, in three launches per panel (nt = ceil(bw/64) tile rows):
+//   part 0  the three tiles of the next panel's diagonal block -- all the next hb2_potrf_kernel needs;
+//   part 1  what the next panel's hb2_trsm_kernel and first update read or overwrite: the rest of the first
+//           128-column block (tiles (ta, 0), (ta, 1), ta >= 2) and the tiles (2,2), (3,2), (3,3) of the diagonal
+//           block after next; its workgroups also copy the finished panel (L11, and P = L21) into the band, which
+//           only the substitutions read -- they are done before the side buffers are reused two panels later;
+//   part 2  everything else (tb >= 2), which only has to precede the same tiles' update by the next panel.
+// Parts 1 and 2 run on a second stream; the main stream waits for part 1 only, so part 2 of panel k overlaps
+// with the diagonal block, triangular solve and first update of panel k + 1.
+// grid (hb2_update_tiles(nt, part) * nprob), workgroup id = tile * nprob + problem: ids of equal residue mod 8
+// share an XCD (observed round-robin placement; speed only), so with nprob a multiple of 8 every L2 serves the
+// 1 MB panels P of nprob / 8 problems instead of all of them; block BG_T.
+__host__ __device__ inline int hb2_update_tiles(int nt, int part) {
+    const int nA0 = nt > 2 ? nt - 2 : 0, ntr = nt * (nt + 1) / 2;
+    const int first = ntr < 3 ? ntr : 3;
+    const int nd = (nt >= 4) ? 3 : ((nt == 3) ? 1 : 0);            // (2,2), (3,2), (3,3) that exist
+    if (part == 0) return first;
+    if (part == 1) return 2 * nA0 + nd > 1 ? 2 * nA0 + nd : 1;     // at least one workgroup: the copies
+    const int m2 = nt > 2 ? nt - 2 : 0;
+    const int rest = m2 * (m2 + 1) / 2 - nd;
+    return rest > 0 ? rest : 0;
+}
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int bw, int n, int k0,
                                                           const double* __restrict__ L11, const double* __restrict__ P,
-                                                          int bwp, int tile0) {
+                                                          int bwp, int part, int nprob) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
-    const int img = blockIdx.y, tid = threadIdx.x;
+    const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
     double* Bi = band + (size_t)img * n * W;
     const double* Pi = P + (size_t)img * bwp * HB2_NB;
-    int ta = 0, t = (int)blockIdx.x + tile0;
-    while (t > ta) { t -= ta + 1; ++ta; }
-    const int tb = t;   // tb <= ta
+    const int nt = (bw + 63) / 64;
+    const int bx = (int)(blockIdx.x / (unsigned)nprob), gx = (int)(gridDim.x / (unsigned)nprob);
+    int ta = -1, tb = -1;   // tile of this workgroup (none: copies only)
+    if (part == 0) {
+        int t = bx; ta = 0;
+        while (t > ta) { t -= ta + 1; ++ta; }
+        tb = t;
+    } else if (part == 1) {
+        const int nA0 = nt > 2 ? nt - 2 : 0;
+        if (bx < nA0) { ta = 2 + bx; tb = 0; }
+        else if (bx < 2 * nA0) { ta = 2 + bx - nA0; tb = 1; }
+        else {
+            const int j = bx - 2 * nA0;
+            if (j == 0 && nt >= 3) { ta = 2; tb = 2; }
+            else if (j == 1 && nt >= 4) { ta = 3; tb = 2; }
+            else if (j == 2 && nt >= 4) { ta = 3; tb = 3; }
+        }
+    } else {
+        int t = bx + ((nt >= 4) ? 3 : ((nt == 3) ? 1 : 0)), a = 0;
+        while (t > a) { t -= a + 1; ++a; }
+        ta = a + 2; tb = t + 2;
+    }
     const int base = k0 + HB2_NB;
-    // Copies of the finished panel into the band (only the substitutions read them): done by the
-    // workgroups of the second launch (tile0 = 3), off the critical path of the next panel's Cholesky.
-    // Explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory latency per iteration.
-    const int bx = (int)blockIdx.x;
-    if (tile0 != 0 && bx == 0) {           // L11
-        const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
-        for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
-            double v[16];
+    // Copies of the finished panel into the band (only the substitutions read them), off the critical path of the
+    // next panel's Cholesky: item 0 = L11, item 1 + t = rows [64 t, 64 t + 64) of L21, dealt round-robin over the
+    // workgroups of part 1.  Explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory
+    // latency per iteration.
+    if (part == 1) {
+        for (int item = bx; item < 1 + nt; item += gx) {
+            if (item == 0) {
+                const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
+                for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
+                    double v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = Lg[e0 + i * BG_T];
+                    for (int i = 0; i < 16; ++i) v[i] = Lg[e0 + i * BG_T];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e = e0 + i * BG_T, r = e % HB2_NB, c = e / HB2_NB;
-                if (r >= c && k0 + r < n && r - c <= bw) Bi[(size_t)(k0 + c) * W + (r - c)] = v[i];
+                    for (int i = 0; i < 16; ++i) {
+                        const int e = e0 + i * BG_T, r = e % HB2_NB, c = e / HB2_NB;
+                        if (r >= c && k0 + r < n && r - c <= bw) Bi[(size_t)(k0 + c) * W + (r - c)] = v[i];
+                    }
+                }
+            } else {
+                const int tc = item - 1;
+                if (base + 64 * tc >= n) continue;
+                for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
+                    double v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int e = e0 + i * BG_T;
+                        v[i] = Pi[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
+                        const int R = base + rr, K = k0 + c;
+                        if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
+                    }
+                }
             }
         }
     }
-    // rows [64 tc, 64 tc + 64) of L21: the diagonal tile tc >= 2 copies its own rows, workgroup 1 of the
-    // second launch those of the row tiles 0 and 1 (whose diagonal tiles belong to the first launch)
-    int tc0 = 0, tc1 = -1;
-    if (tile0 != 0 && bx == 1) { tc0 = 0; tc1 = 1; }
-    else if (tile0 != 0 && ta == tb) { tc0 = ta; tc1 = ta; }
-    for (int tc = tc0; tc <= tc1; ++tc) {
-        if (base + 64 * tc >= n) break;
-        for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
-            double v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e = e0 + i * BG_T;
-                v[i] = Pi[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
-                const int R = base + rr, K = k0 + c;
-                if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
-            }
-        }
-    }
+    if (ta < 0 || ta >= nt) return;
     if (base + 64 * tb >= n) return;
     if (base + 64 * ta >= n) return;
     double* As = lds;

@@ -783,7 +783,12 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     // Refinement sweeps: every sweep gains ~2 digits with the 1e14 active-set weight of the scalar gradient and
     // 4-5 digits with the 6.7e7 / 1e8 weights of the patch and regularised gradients, where the second sweep
     // already reaches rounding level (tools/gpu_refine.py).
-    const int nref = p.refine < 0 ? ((patch || reg) ? 2 : 3) : p.refine;
+    // The HBM band path factors with true triangular solves (only its 128 x 128 diagonal blocks are inverted): one
+    // sweep already reaches the level the block-cyclic-reduction path needs two for (tools/gpu_refine_hbm.py,
+    // 1024^2: pixel map 3.6e-9 / patch 6e-11 / regularised 1e-16 from the converged value after ONE sweep, scalar
+    // 1.4e-9 after two), and every sweep costs two full substitutions of the 8.6 GB factor.
+    const int nref_default = (method == ADJ_BAND_HBM) ? ((patch || reg) ? 1 : 2) : ((patch || reg) ? 2 : 3);
+    const int nref = p.refine < 0 ? nref_default : p.refine;
     AdjCoef C;
     C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;
     C.h1 = h->d_coef + 4 * tot; C.h2 = h->d_coef + 5 * tot; C.s = h->d_coef + 6 * tot; C.rhs = h->d_coef + 7 * tot;

@@ -59,7 +59,7 @@ struct HbBandSolver {
     };
     static size_t bufs_doubles(int nprob, int ncol, int bw) {
         const size_t npanel = (size_t)(ncol + HB2_NB - 1) / HB2_NB, bwp = (size_t)(bw + 63) / 64 * 64;
-        return (size_t)nprob * ((2 * npanel + 2) * HB2_NB * HB2_NB + bwp * HB2_NB);
+        return (size_t)nprob * ((2 * npanel + 2) * HB2_NB * HB2_NB + 2 * bwp * HB2_NB);
     }
     static Bufs carve(double* base, int nprob, int ncol) {
         Bufs b;
@@ -68,7 +68,7 @@ struct HbBandSolver {
         b.Linv = base;
         b.LinvT = base + blk * b.npanel;
         b.L11 = b.LinvT + blk * b.npanel;   // two buffers (panel parity)
-        b.P = b.L11 + 2 * blk;
+        b.P = b.L11 + 2 * blk;              // two buffers of nprob * bwp * 128 doubles (panel parity)
         return b;
     }
 
@@ -123,7 +123,11 @@ struct HbBandSolver {
         }
         HBCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bcr_potrf_lds(HB2_NB)));
-        HBCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        {   // the bulk of the trailing update yields to the dependent chain on the main stream
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HBCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least));
+        }
         for (auto& e : ev) HBCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return 0;
     }
@@ -137,37 +141,41 @@ struct HbBandSolver {
         stream2 = nullptr;
     }
 
-    // Right-looking blocked Cholesky of `nprob` band problems of `nrow` rows, eliminating columns [0, nelim):
-    // per panel of 128 columns potrf -> trsm -> first three update tiles (the next diagonal block), the rest of
-    // the trailing update on a second stream beside the next panel's (latency-bound, nprob-workgroup) potrf.
+    // Right-looking blocked Cholesky of `nprob` band problems of `nrow` rows, eliminating columns [0, nelim).
+    // Main stream, per panel of 128 columns: potrf -> [part 1 of the previous panel's update done] -> trsm ->
+    // update part 0 (the next diagonal block).  Second stream: update part 1 (what the next trsm needs, and the
+    // copies of the finished panel), then part 2 (the bulk), which overlaps with the next panel's chain.
+    // Side buffers L11 and P alternate by panel parity: panel k+1 writes them while part 2 of panel k still reads.
     int factor_problems(double* B, int nprob, int nrow, int nelim, const Bufs& hb, int* d_fail) {
-        const int nt = (bw + 63) / 64, ntile = nt * (nt + 1) / 2, bwp = nt * 64;
-        bool rest_pending = false;
+        const int nt = (bw + 63) / 64, bwp = nt * 64;
+        const int g0 = hb2_update_tiles(nt, 0), g1 = hb2_update_tiles(nt, 1), g2 = hb2_update_tiles(nt, 2);
+        bool part1_pending = false;
         hipStream_t s2 = single_stream ? stream : stream2;
         for (int k0 = 0; k0 < nelim; k0 += HB2_NB) {
-            double* L11p = hb.L11 + (size_t)((k0 / HB2_NB) & 1) * nprob * HB2_NB * HB2_NB;
+            const int par = (k0 / HB2_NB) & 1;
+            double* L11p = hb.L11 + (size_t)par * nprob * HB2_NB * HB2_NB;
+            double* Pp = hb.P + (size_t)par * nprob * bwp * HB2_NB;
             hipLaunchKernelGGL(hb2_potrf_kernel, dim3(nprob), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, B, bw, nrow, k0,
                                hb.npanel, hb.Linv, hb.LinvT, L11p, d_fail);
-            if (rest_pending && !single_stream) {   // the previous panel's trailing update must be complete from here on
-                HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
-            }
-            rest_pending = false;
+            if (part1_pending && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+            part1_pending = false;
             if (k0 + HB2_NB < nrow)
-                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt, nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, hb.npanel, hb.Linv,
-                                   hb.P, bwp);
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(std::min(3, ntile), nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, hb.P,
-                               bwp, 0);
-            if (ntile > 3) {
-                if (!single_stream) {
-                    HBCHK(hipEventRecord(ev[0], stream));
-                    HBCHK(hipStreamWaitEvent(s2, ev[0], 0));
-                }
-                hipLaunchKernelGGL(hb2_update_kernel, dim3(ntile - 3, nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, hb.P, bwp, 3);
-                if (!single_stream) HBCHK(hipEventRecord(ev[1], s2));
-                rest_pending = true;
+                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, hb.npanel, hb.Linv, Pp,
+                                   bwp, nprob);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, Pp, bwp, 0, nprob);
+            if (!single_stream) {
+                HBCHK(hipEventRecord(ev[0], stream));
+                HBCHK(hipStreamWaitEvent(s2, ev[0], 0));
             }
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 1, nprob);
+            if (!single_stream) HBCHK(hipEventRecord(ev[1], s2));
+            part1_pending = true;
+            if (g2 > 0) hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 2, nprob);
         }
-        if (rest_pending && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+        if (!single_stream) {   // join: everything on the second stream is complete before the caller continues
+            HBCHK(hipEventRecord(ev[1], s2));
+            HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+        }
         HBCHK(hipGetLastError());
         return 0;
     }

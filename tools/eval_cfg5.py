@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe: BASELINE config 5's share of one GPU through the learning function -- 8 x 1024 x 1024,
 pixelwise alpha, PDHG (short) + loss + HBM-band adjoint.  For rocprofv3 --kernel-trace / --pmc and timing.
-usage: eval_cfg5.py [images] [repeats] [maxiter]"""
+usage: eval_cfg5.py [images] [repeats] [maxiter] [size]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +11,7 @@ from conftest import synth_batch
 O = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 maxiter = int(sys.argv[3]) if len(sys.argv) > 3 else 400
-n = 1024
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 ub, f = synth_batch(O, n, n, seed=3)
 jj, ii = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
 amap = 0.11 + 0.09 * np.sin(2 * np.pi * ii / n) * np.cos(2 * np.pi * jj / n)
