@@ -67,6 +67,9 @@ SYMBOLS = {
     "bpltv_set_data_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "bpltv_denoise": (C.c_int, [_H, _dp, C.c_int, C.c_int, _PP, _dp]),
     "bpltv_evaluate": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_double, _PP, _dp, _dp, _dp]),
+    "bpltv_sumregs_default_params": (C.c_int, [_PP]),
+    "bpltv_sumregs_denoise": (C.c_int, [_H, _dp, C.c_int, C.c_int, _PP, _dp]),
+    "bpltv_sumregs_evaluate": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_double, _PP, _dp, _dp, _dp]),
     "bpltv_evaluate_partial": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_double, _PP, _dp, _dp]),
     "bpltv_evaluate_device": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_double, _PP, C.c_void_p]),
     "bpltv_u_device": (C.c_int, [_H, C.POINTER(C.c_void_p)]),

@@ -21,6 +21,7 @@
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
+#include "sumregs_kernels.hpp"
 #include "multi_gpu.hpp"
 
 using namespace bpltv;
@@ -81,8 +82,17 @@ struct GraphKey {
 struct TabKey {
     int maxiter, accel;
     double tau0, sigma0;
+    double L2;   // squared operator-norm bound the steps are divided by: 8 (TV), 18 (sum of regularisers)
     bool operator<(const TabKey& o) const {
-        return std::tie(maxiter, accel, tau0, sigma0) < std::tie(o.maxiter, o.accel, o.tau0, o.sigma0);
+        return std::tie(maxiter, accel, tau0, sigma0, L2) < std::tie(o.maxiter, o.accel, o.tau0, o.sigma0, o.L2);
+    }
+};
+
+struct SrGraphKey {
+    int maxiter, T, am, an, accel;
+    double rho, tau0, sigma0;
+    bool operator<(const SrGraphKey& o) const {
+        return std::tie(maxiter, T, am, an, accel, rho, tau0, sigma0) < std::tie(o.maxiter, o.T, o.am, o.an, o.accel, o.rho, o.tau0, o.sigma0);
     }
 };
 
@@ -141,6 +151,16 @@ struct bpltv_handle {
     double* d_resn = nullptr;
     int* d_fail = nullptr;
     double *d_u2 = nullptr, *d_ubar2 = nullptr;  // staging for bpltv_gradient
+    // sum-of-regularisers model (sumregs_kernels.hpp): state and adjoint workspace, allocated on first use
+    double* d_sr[2][7] = {{nullptr}, {nullptr}};   // x, yf1, yf2, yb1, yb2, yc1, yc2; two sets (ping-pong)
+    bool sr_ready = false, sr_adj_ready = false;
+    int last_slices = 1;                            // parameter slices of the last evaluate: 1 (TV) or 3
+    int sr_result_buf = 0;
+    bool sr_has_result = false;
+    bool last_is_sr = false;                        // the last solve was the sum-of-regularisers model
+    double *d_srcoef = nullptr, *d_srdiag = nullptr, *d_srw = nullptr, *d_srgpix = nullptr;
+    HbBandSolver hb_sr;
+    std::map<SrGraphKey, hipGraphExec_t> sr_graphs;
     bpltv_stats_t st;
     std::string err;
 };
@@ -186,8 +206,8 @@ int ensure(bpltv_t* h, double** p, size_t* cap, size_t need) {
 }
 
 void fill_table(const TabKey& k, std::vector<double>& tab) {
-    // oracle/bpltv_oracle.c: bplo_step_table (same operations, same order)
-    const double L = std::sqrt(8.0);
+    // oracle/bpltv_oracle.c: bplo_step_table_L (same operations, same order)
+    const double L = std::sqrt(k.L2);
     double tau = k.tau0 / L, sigma = k.sigma0 / L;
     const double gamma = 1.0;
     tab.assign((size_t)TAB_STRIDE * (k.maxiter > 0 ? k.maxiter : 1), 0.0);
@@ -206,8 +226,8 @@ void fill_table(const TabKey& k, std::vector<double>& tab) {
     }
 }
 
-int get_table(bpltv_t* h, const bpltv_params& p, double** out) {
-    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0};
+int get_table(bpltv_t* h, const bpltv_params& p, double** out, double L2 = 8.0) {
+    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, L2};
     auto it = h->tabs.find(k);
     if (it != h->tabs.end()) {
         *out = it->second;
@@ -256,6 +276,7 @@ int upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
     HIPCHK(h, hipMemcpyAsync(h->d_alpha, alpha, need * sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->last_am = am;
     h->last_an = an;
+    h->last_slices = 1;
     return BPLTV_OK;
 }
 
@@ -561,6 +582,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->st.launches = launches;
     h->result_buf = buf;
     h->has_result = true;
+    h->last_is_sr = false;
     const bool amap = (h->last_am == h->M && h->last_an == h->N) && !(h->M == 1 && h->N == 1);
     h->st.bytes_per_px_iter = amap ? 64.0 : 56.0;
     h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->npx * h->cur_nimg * h->st.iterations;
@@ -954,6 +976,292 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
 
 
 // ============================================================================================
+// Sum-of-regularisers model (sumregs_kernels.hpp; /root/reference/src/SumRegsLearningFunction.jl)
+// ============================================================================================
+constexpr int SR_R = 32;   // region of sr_tile_kernel<32, 32>: one pixel per thread
+
+int sr_upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
+    if (!alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
+    if (am > h->M || an > h->N) return set_err(h, BPLTV_E_ARG, "alpha shape %dx%dx3 exceeds image %dx%d", am, an, h->M, h->N);
+    const size_t need = 3 * (size_t)am * an;
+    double amin = alpha[0];
+    for (size_t e = 0; e < need; ++e) {
+        if (!std::isfinite(alpha[e]) || alpha[e] < 0.0)
+            return set_err(h, BPLTV_E_ARG, "alpha[%zu] = %g: parameters must be finite and >= 0", e, alpha[e]);
+        if (alpha[e] < amin) amin = alpha[e];
+    }
+    h->alpha_min = amin;
+    if (h->alpha_cap < need) {
+        drop_graphs(h);
+        for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+        h->sr_graphs.clear();
+        int rc = ensure(h, &h->d_alpha, &h->alpha_cap, need);
+        if (rc) return rc;
+    }
+    if (h->partial_cap < need + 1) {
+        int rc = ensure(h, &h->d_partial, &h->partial_cap, need + 1);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_alpha, alpha, need * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->last_am = am; h->last_an = an; h->last_slices = 3;
+    return BPLTV_OK;
+}
+
+int sr_alloc(bpltv_t* h) {
+    if (h->sr_ready) return BPLTV_OK;
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 7; ++c) HIPCHK(h, hipMalloc((void**)&h->d_sr[s][c], h->tot * sizeof(double)));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_tile_kernel<SR_R, SR_R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sr_lds_bytes(SR_R, SR_R)));
+    h->sr_ready = true;
+    return BPLTV_OK;
+}
+
+// maxiter iterations of the three-dual PDHG, T fused per launch (halo 2T), replayed from a hipGraph.
+int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
+    h->has_per_image = false;
+    if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
+    if (p.maxiter < 0) return set_err(h, BPLTV_E_ARG, "maxiter < 0");
+    if (p.rho != 0.0 && !(h->alpha_min > 0.0))
+        return set_err(h, BPLTV_E_ARG, "rho != 0 divides by alpha: every parameter entry must be > 0 (min = %g)", h->alpha_min);
+    int rc = sr_alloc(h);
+    if (rc) return rc;
+    double* d_tab = nullptr;
+    rc = get_table(h, p, &d_tab, 18.0);   // ||G_f||^2 + ||G_b||^2 + ||G_c||^2 <= 8 + 8 + 2 (sumregs_oracle.c: SR_L)
+    if (rc) return rc;
+    const int M = h->M, N = h->N;
+    int T = p.tile_iters > 0 ? p.tile_iters : 4;   // halo 8, core 16 of the 32 x 32 region
+    auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 4; };   // 2 * halo = 4T must leave a core
+    T = std::min(T, std::min(maxT(M, SR_R), maxT(N, SR_R)));
+    if (T < 1) return set_err(h, BPLTV_E_ARG, "tile_iters must be >= 1");
+    const int nTi = tile_count(M, SR_R, 2 * T), nTj = tile_count(N, SR_R, 2 * T);
+    if (nTi < 1 || nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
+    const int grid = nTi * nTj * h->O;
+    h->st.tile_iters = T; h->st.tiles = grid; h->st.region_i = SR_R; h->st.region_j = SR_R;
+    h->st.launches = 0; h->st.iterations = p.maxiter; h->st.graph_used = 0; h->st.last_gap = -1.0;
+    if (p.maxiter == 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_sr[0][0], h->d_f, h->tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        for (int c = 1; c < 7; ++c) HIPCHK(h, hipMemsetAsync(h->d_sr[0][c], 0, h->tot * sizeof(double), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->sr_result_buf = 0; h->sr_has_result = true; h->last_is_sr = true; h->st.pdhg_ms = 0.0;
+        return BPLTV_OK;
+    }
+    auto enqueue = [&](hipStream_t st) -> int {   // returns the state set holding the result
+        int cur = 0;
+        for (int it = 0; it < p.maxiter; it += T) {
+            SrArgs a;
+            const int nxt = (it == 0) ? 0 : 1 - cur;
+            for (int c = 0; c < 7; ++c) { a.in[c] = h->d_sr[cur][c]; a.out[c] = h->d_sr[nxt][c]; }
+            a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
+            a.am = h->last_am; a.an = h->last_an;
+            a.it0 = it; a.nit = std::min(T, p.maxiter - it);
+            a.M = M; a.N = N; a.O = h->O; a.nTi = nTi; a.nTj = nTj; a.halo = 2 * T;
+            a.first = (it == 0) ? 1 : 0;
+            hipLaunchKernelGGL((sr_tile_kernel<SR_R, SR_R>), dim3(grid), dim3(SR_R * SR_R), sr_lds_bytes(SR_R, SR_R), st, a);
+            cur = nxt;
+        }
+        return cur;
+    };
+    const int nl = (p.maxiter + T - 1) / T;
+    const int buf = (nl - 1) % 2 == 0 ? 0 : 1;   // launch 0 writes set 0, launch l writes set l % 2
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    bool done = false;
+    if (p.use_graph && nl <= 50000) {
+        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, p.rho, p.tau0, p.sigma0};
+        auto it = h->sr_graphs.find(key);
+        if (it == h->sr_graphs.end()) {
+            if (h->sr_graphs.size() >= 8) {
+                for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+                h->sr_graphs.clear();
+            }
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ex = nullptr;
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                (void)enqueue(h->stream);
+                if (hipStreamEndCapture(h->stream, &g) == hipSuccess && g &&
+                    hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+                    h->sr_graphs[key] = ex;
+                    it = h->sr_graphs.find(key);
+                }
+                if (g) (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();
+        }
+        if (it != h->sr_graphs.end()) {
+            HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+            h->st.graph_used = 1;
+            done = true;
+        }
+    }
+    if (!done) (void)enqueue(h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->st.pdhg_ms = ms;
+    h->st.launches = nl;
+    h->sr_result_buf = buf;
+    h->sr_has_result = true;
+    h->last_is_sr = true;
+    const bool amap = (h->last_am == M && h->last_an == N) && !(M == 1 && N == 1);
+    h->st.bytes_per_px_iter = amap ? 144.0 : 120.0;   // read x, 6 y, f (+ 3 alpha), write x, 6 y
+    h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->tot * p.maxiter;
+    return BPLTV_OK;
+}
+
+int sr_adj_alloc(bpltv_t* h) {
+    int rc = adj_alloc(h);   // d_p, d_r, d_gpix, d_resn, d_fail
+    if (rc) return rc;
+    if (h->sr_adj_ready) return BPLTV_OK;
+    const size_t tot = h->tot;
+    size_t freeb = 0, totalb = 0;
+    (void)hipMemGetInfo(&freeb, &totalb);
+    const int n = (int)h->npx, bw = std::min(2 * h->M, n - 1);
+    const size_t need = h->hb_sr.bytes_needed(bw, n, h->O) + (19 + 7 + 6 + 3) * tot * sizeof(double);
+    if (need + (2ull << 30) > freeb)
+        return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint: %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
+    HIPCHK(h, hipMalloc((void**)&h->d_srcoef, 19 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_srdiag, 7 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_srw, 6 * tot * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_srgpix, 3 * tot * sizeof(double)));
+    rc = h->hb_sr.alloc(bw, n, h->O, h->stream);
+    if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    h->sr_adj_ready = true;
+    return BPLTV_OK;
+}
+
+int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p, double* d_out,
+                         double kappa_scale) {
+    int rc = sr_adj_alloc(h);
+    if (rc) return rc;
+    const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
+    const size_t tot = h->tot, P = (size_t)am * an;
+    const int patch = !(am == 1 && an == 1);
+    if (reg && patch)
+        return set_err(h, BPLTV_E_UNSUPPORTED, "sumregs_gradient_reg with a patch parameter (SumRegsLearningFunction.jl:195-262) row-scales three operators differently: the system is not symmetric and has no GPU factorisation here yet");
+    double kact = 1.0 / 2.220446049250313e-16;   // eps() in the vector AND the patch variant (:319, :389)
+    const double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
+    if (kact > kcap) kact = kcap;
+    kact *= kappa_scale;
+    const int nref = p.refine < 0 ? (reg ? 1 : 2) : p.refine;
+    SrCoef C;
+    C.tot = tot;
+    C.t1 = h->d_srcoef; C.t2 = h->d_srcoef + 3 * tot; C.c = h->d_srcoef + 6 * tot; C.kap = h->d_srcoef + 9 * tot;
+    C.h1 = h->d_srcoef + 12 * tot; C.h2 = h->d_srcoef + 15 * tot; C.rhs = h->d_srcoef + 18 * tot;
+    const int gpx = (int)((tot + 255) / 256);
+    HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(sr_adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N, O, patch, reg,
+                       kact, C);
+    hipLaunchKernelGGL(sr_adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_srdiag);
+    HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
+    BandDiags D;
+    D.planes = h->d_srdiag; D.tot = tot; D.nd = 7;
+    D.off[0] = 0; D.off[1] = 1; D.off[2] = 2; D.off[3] = M - 1; D.off[4] = M; D.off[5] = M + 1; D.off[6] = 2 * M;
+    rc = h->hb_sr.factor(D, h->d_fail);
+    if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    auto residual = [&](double* out) {
+        hipLaunchKernelGGL(sr_adj_flux_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_srw);
+        hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, h->d_srw, M, N, O, out);
+    };
+    HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->hb_sr.solve(h->d_p, nullptr, h->d_gpix);
+    for (int it = 0; it < nref; ++it) {
+        residual(h->d_r);
+        h->hb_sr.solve(h->d_r, h->d_p, h->d_gpix);
+    }
+    residual(h->d_r);
+    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_srdiag, (int)h->npx, h->d_resn);
+    hipLaunchKernelGGL(sr_adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg, h->d_srgpix);
+    if (am == M && an == N && !(M == 1 && N == 1)) {   // three pixelwise maps: plain sums over the images
+        for (int k = 0; k < 3; ++k)
+            hipLaunchKernelGGL(map_sum_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, h->stream, h->d_srgpix + k * tot,
+                               h->npx, O, d_out + (size_t)k * h->npx);
+    } else {
+        rc = ensure(h, &h->d_red, &h->red_cap, 3 * P * O);
+        if (rc) return rc;
+        for (int k = 0; k < 3; ++k)
+            hipLaunchKernelGGL(patch_sum_kernel, dim3((unsigned)P, O), dim3(256), 0, h->stream, h->d_srgpix + k * tot, M, N, O, am, an,
+                               h->d_red + (size_t)k * P * O);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, O, (int)(3 * P), 1.0, d_out, (double*)nullptr);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    std::vector<int> fail(O);
+    std::vector<double> resn(4 * (size_t)O);
+    HIPCHK(h, hipMemcpyAsync(fail.data(), h->d_fail, sizeof(int) * O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(resn.data(), h->d_resn, sizeof(double) * 4 * O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    h->st.adjoint_ms = ms;
+    h->st.reg_gradient_used = reg;
+    h->st.adjoint_method = (int)ADJ_BAND_HBM;
+    h->st.kappa_used = reg ? 0.0 : kact;
+    double worst = 0.0, worst_raw = 0.0;
+    for (int k = 0; k < O; ++k) {
+        if (fail[k] != 0)
+            return set_err(h, BPLTV_E_NUMERIC, "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d", fail[k] - 1, k);
+        const double* q = &resn[4 * (size_t)k];
+        const double raw = std::sqrt(q[0]) / (q[1] > 0 ? std::sqrt(q[1]) : 1.0);
+        const double scl = std::sqrt(q[2]) / (q[3] > 0 ? std::sqrt(q[3]) : 1.0);
+        if (!(raw <= worst_raw)) worst_raw = raw;
+        if (!(scl <= worst)) worst = scl;
+    }
+    h->st.adjoint_residual = worst;
+    h->st.adjoint_residual_raw = worst_raw;
+    if (!(worst <= BPLTV_RESIDUAL_GATE))
+        return set_err(h, BPLTV_E_NUMERIC, "sum-of-regularisers adjoint solve: scaled residual %.3e above the gate %.1e", worst,
+                       (double)BPLTV_RESIDUAL_GATE);
+    return BPLTV_OK;
+}
+
+int run_sr_gradient(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p, double* d_out) {
+    double scale = 1.0;
+    int rc = BPLTV_OK;
+    h->st.adjoint_attempts = 0;
+    for (int attempt = 0; attempt < 3; ++attempt, scale *= 1e-2) {
+        rc = run_sr_gradient_once(h, d_u, d_ubar, reg, p, d_out, scale);
+        h->st.adjoint_attempts = attempt + 1;
+        if (rc != BPLTV_E_NUMERIC || reg) break;
+    }
+    if (rc == BPLTV_OK) h->err.clear();
+    return rc;
+}
+
+// sumregs_learning_function(x, data, D): SumRegsLearningFunction.jl:8-36.  partial: [cost, grad (3*am*an)...]
+int sr_evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* pp, double* u_out,
+                       double* partial_host) {
+    if (!h) return BPLTV_E_ARG;
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
+    int rc = sr_upload_alpha(h, alpha, am, an);
+    if (rc) return rc;
+    rc = run_sr_pdhg(h, p);
+    if (rc) return rc;
+    const double* d_u = h->d_sr[h->sr_result_buf][0];
+    HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    rc = compute_cost(h, d_u, h->d_ubar, h->d_partial);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+    const int reg = !(delta > p.delta_t);   // SumRegsLearningFunction.jl:14-18, 30-34
+    rc = run_sr_gradient(h, d_u, h->d_ubar, reg, p, h->d_partial + 1);
+    if (rc) return rc;
+    const size_t np = 1 + 3 * (size_t)am * an;
+    if (partial_host) HIPCHK(h, hipMemcpyAsync(partial_host, h->d_partial, np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u_out) HIPCHK(h, hipMemcpyAsync(u_out, d_u, h->tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[4], h->ev[5]));
+    h->st.cost_ms = ms;
+    h->st.total_ms = wt.ms();
+    h->has_per_image = !(am == h->M && an == h->N && !(h->M == 1 && h->N == 1));
+    return BPLTV_OK;
+}
+
+// ============================================================================================
 // Multi-device handle (multi_gpu.hpp): every entry point fans out to the shards' worker threads.
 // ============================================================================================
 #define NCCLCHK(h, call)                                                                            \
@@ -1085,12 +1393,13 @@ int multi_set_data(bpltv_t* h, const double* ubar, const double* f) {
     return rc;
 }
 
-int multi_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out) {
+int multi_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out, int slices = 1) {
     WallTimer wt;
     MultiState& ms = *h->multi;
     const size_t npx = h->npx;
     int rc = multi_run(h, [&](int k, bpltv_t* c) {
-        return bpltv_denoise(c, alpha, am, an, pp, u_out ? u_out + ms.lo[k] * npx : nullptr);
+        double* uo = u_out ? u_out + ms.lo[k] * npx : nullptr;
+        return slices == 3 ? bpltv_sumregs_denoise(c, alpha, am, an, pp, uo) : bpltv_denoise(c, alpha, am, an, pp, uo);
     });
     if (rc) return rc;
     h->has_result = true;
@@ -1102,14 +1411,16 @@ int multi_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_p
 // tv_op_learning_function over the shards: every device evaluates its images, then ONE collective on the
 // [cost, grad...] vector.  out: host, 1 + am*an doubles.
 int multi_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* pp,
-                   double* u_out, double* out) {
+                   double* u_out, double* out, int slices = 1) {
     WallTimer wt;
     MultiState& ms = *h->multi;
     const int n = (int)ms.shard.size();
-    const size_t npx = h->npx, P = (size_t)am * an, np = 1 + P;
+    const size_t npx = h->npx, P = (size_t)am * an * slices, np = 1 + P;
     const bpltv_params p = resolve(pp);
     int rc = multi_run(h, [&](int k, bpltv_t* c) {
-        return evaluate_common(c, alpha, am, an, delta, pp, u_out ? u_out + ms.lo[k] * npx : nullptr, nullptr, nullptr);
+        double* uo = u_out ? u_out + ms.lo[k] * npx : nullptr;
+        return slices == 3 ? sr_evaluate_common(c, alpha, am, an, delta, pp, uo, nullptr)
+                           : evaluate_common(c, alpha, am, an, delta, pp, uo, nullptr, nullptr);
     });
     if (rc) return rc;
     const bool amap = (am == h->M && an == h->N) && !(h->M == 1 && h->N == 1);
@@ -1195,7 +1506,7 @@ int multi_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta
     h->st.collective_ms = ct.ms();
     h->has_result = true;
     h->has_per_image = !amap;
-    h->last_am = am; h->last_an = an;
+    h->last_am = am; h->last_an = an; h->last_slices = slices;
     h->st.total_ms = wt.ms();
     return multi_stats(h);
 }
@@ -1368,6 +1679,13 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->hb.release();
+    h->hb_sr.release();
+    for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void* q : {(void*)h->d_srcoef, (void*)h->d_srdiag, (void*)h->d_srw, (void*)h->d_srgpix})
+        if (q) (void)hipFree(q);
+    for (int s2 = 0; s2 < 2; ++s2)
+        for (int c = 0; c < 7; ++c)
+            if (h->d_sr[s2][c]) (void)hipFree(h->d_sr[s2][c]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return BPLTV_OK;
@@ -1435,6 +1753,49 @@ int bpltv_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta
     return BPLTV_OK;
 }
 
+int bpltv_sumregs_default_params(bpltv_params* p) {
+    const int rc = bpltv_default_params(p);   // same solver block (SumRegsLearningFunction.jl:39-55 == TVLearningFunctionVec.jl:33-43)
+    if (rc) return rc;
+    p->delta_t = 1e-3;                        // SumRegsLearningFunction.jl:8,22
+    return BPLTV_OK;
+}
+
+int bpltv_sumregs_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (h->multi) return multi_denoise(h, alpha, am, an, pp, u_out, 3);
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p;
+    if (pp) p = *pp; else bpltv_sumregs_default_params(&p);
+    if (int prc = check_params(h, p)) return prc;
+    int rc = sr_upload_alpha(h, alpha, am, an);
+    if (rc) return rc;
+    rc = run_sr_pdhg(h, p);
+    if (rc) return rc;
+    if (u_out) {
+        HIPCHK(h, hipMemcpyAsync(u_out, h->d_sr[h->sr_result_buf][0], h->tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_sumregs_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* pp, double* u_out,
+                           double* cost_out, double* grad_out) {
+    if (!h) return BPLTV_E_ARG;
+    if (!cost_out || !grad_out) return set_err(h, BPLTV_E_ARG, "evaluate: null output pointer");
+    if (!alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
+    bpltv_params p;
+    if (pp) p = *pp; else bpltv_sumregs_default_params(&p);
+    std::vector<double> part(1 + 3 * (size_t)am * an);
+    int rc = h->multi ? multi_evaluate(h, alpha, am, an, delta, &p, u_out, part.data(), 3)
+                      : sr_evaluate_common(h, alpha, am, an, delta, &p, u_out, part.data());
+    if (rc) return rc;
+    *cost_out = part[0];
+    std::memcpy(grad_out, part.data() + 1, sizeof(double) * 3 * (size_t)am * an);
+    return BPLTV_OK;
+}
+
 int bpltv_evaluate_partial(bpltv_t* h, const double* alpha, int am, int an, double delta, const bpltv_params* p,
                            double* u_out, double* partial_out) {
     if (!h) return BPLTV_E_ARG;
@@ -1469,6 +1830,7 @@ int bpltv_u_device(bpltv_t* h, const double** d_u) {
         if (r) h->err = h->multi->shard[0]->err;
         return r;
     }
+    if (h->last_is_sr && h->sr_has_result) { *d_u = h->d_sr[h->sr_result_buf][0]; return BPLTV_OK; }
     if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     *d_u = h->d_state[h->result_buf][0];
     return BPLTV_OK;
@@ -1483,10 +1845,11 @@ int bpltv_copy_u_device(bpltv_t* h, double* d_dst) {
         if (r) h->err = h->multi->shard[0]->err;
         return r;
     }
-    if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
+    const bool sr = h->last_is_sr && h->sr_has_result;
+    if (!sr && !h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(d_dst, h->d_state[h->result_buf][0], h->tot * sizeof(double), hipMemcpyDeviceToDevice,
-                             h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_dst, sr ? h->d_sr[h->sr_result_buf][0] : h->d_state[h->result_buf][0], h->tot * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return BPLTV_OK;
 }
@@ -1498,6 +1861,7 @@ int bpltv_duality_gap(bpltv_t* h, double* gap_out) {
         const int rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_duality_gap(c, gap_out + ms.lo[k]); });
         return rc ? rc : multi_stats(h);
     }
+    if (h->last_is_sr) return set_err(h, BPLTV_E_UNSUPPORTED, "the duality gap is implemented for the TV model only");
     if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     HIPCHK(h, hipSetDevice(h->device));
     double gmax = 0.0;
@@ -1652,13 +2016,13 @@ int bpltv_per_image(bpltv_t* h, double* out) {
         if (!h->has_per_image)
             return set_err(h, BPLTV_E_UNSUPPORTED, "per-image pieces exist after evaluate with a scalar or patch parameter only");
         MultiState& ms = *h->multi;
-        const size_t W = 1 + (size_t)h->last_am * h->last_an;
+        const size_t W = 1 + (size_t)h->last_am * h->last_an * h->last_slices;
         return multi_run(h, [&](int k, bpltv_t* c) { return bpltv_per_image(c, out + ms.lo[k] * W); });
     }
     if (!h->has_per_image)
         return set_err(h, BPLTV_E_UNSUPPORTED, "per-image pieces exist after evaluate with a scalar or patch parameter only");
     HIPCHK(h, hipSetDevice(h->device));
-    const int O = h->O, P = h->last_am * h->last_an;
+    const int O = h->O, P = h->last_am * h->last_an * h->last_slices;
     std::vector<double> cost(O), g((size_t)P * O);
     HIPCHK(h, hipMemcpy(cost.data(), h->d_perimg, sizeof(double) * O, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(g.data(), h->d_red, sizeof(double) * P * O, hipMemcpyDeviceToHost));   // [patch][image]

@@ -35,6 +35,16 @@ def _alpha_arg(x):
     return a, am, an, False
 
 
+def _sr_alpha_arg(x):
+    """Sum-of-regularisers parameter: Julia Vector [a1; a2; a3] == numpy (3,); Julia m x n x 3 == numpy (3, n, m)."""
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if a.ndim == 1 and a.shape[0] == 3:
+        return a, 1, 1, True
+    if a.ndim == 3 and a.shape[0] == 3:
+        return a, a.shape[2], a.shape[1], False
+    raise ValueError("sum-of-regularisers parameter must have shape (3,) or (3, n, m), got %s" % (a.shape,))
+
+
 class FwdGradientOp:
     """Marker for the forward-difference gradient operator (Neumann boundary), the only operator
     the reference passes on this path (/root/reference/src/TVLearningFunctionVec.jl:17)."""
@@ -93,9 +103,9 @@ class TVSolver:
         except Exception:
             pass
 
-    def params(self, **kw):
+    def params(self, _sumregs=False, **kw):
         p = _lib.BpltvParams()
-        self._lib.bpltv_default_params(C.byref(p))
+        (self._lib.bpltv_sumregs_default_params if _sumregs else self._lib.bpltv_default_params)(C.byref(p))
         variant = kw.pop("variant", None)
         chains = kw.pop("chains", None)
         serialize = kw.pop("serialize_chains", None)
@@ -174,6 +184,28 @@ class TVSolver:
         p = self.params(**kw)
         self._check(self._lib.bpltv_evaluate_device(self._h, _ptr(a), am, an, float(delta), C.byref(p),
                                                     C.c_void_p(partial_ptr)))
+
+    # -- sum-of-regularisers model (/root/reference/src/SumRegsLearningFunction.jl) ----------------------
+    def sumregs_denoise(self, x, fetch=True, **kw):
+        """sumregs_denoise(data, x, op1, op2, op3[, pOp]) (:38-85).  x: (3,) vector or (3, n, m) patch parameter
+        (numpy (3, n, m) == Julia m x n x 3)."""
+        a, am, an, _ = _sr_alpha_arg(x)
+        p = self.params(_sumregs=True, **kw)
+        u = np.empty((self.O, self.N, self.M)) if fetch else None
+        self._check(self._lib.bpltv_sumregs_denoise(self._h, _ptr(a), am, an, C.byref(p), _ptr(u) if fetch else None))
+        return u
+
+    def sumregs_evaluate(self, x, delta, fetch_u=True, **kw):
+        """sumregs_learning_function(x, data, D; Dt = 1e-3) -> (u, cost, grad) (:8-36); grad has the shape of x."""
+        a, am, an, vec = _sr_alpha_arg(x)
+        self._last_npar = 3 * am * an
+        p = self.params(_sumregs=True, **kw)
+        u = np.empty((self.O, self.N, self.M)) if fetch_u else None
+        cost = C.c_double(0.0)
+        grad = np.empty(3 * am * an)
+        self._check(self._lib.bpltv_sumregs_evaluate(self._h, _ptr(a), am, an, float(delta), C.byref(p),
+                                                     _ptr(u) if fetch_u else None, C.byref(cost), _ptr(grad)))
+        return u, cost.value, (grad.copy() if vec else grad.reshape(3, an, am))
 
     def gradient(self, u, ubar, x, reg=False, **kw):
         a, am, an, scalar = _alpha_arg(x)
@@ -306,6 +338,19 @@ def denoise(data, x, op=None, **kwargs):
         raise TypeError("only FwdGradientOp is supported on this path")
     s = _solver_for(None, data)
     return s.denoise(x, **kwargs)
+
+
+def sumregs_learning_function(x, data, Δ, Δt=1e-3, **kwargs):
+    """(u, cost, grad) -- /root/reference/src/SumRegsLearningFunction.jl:8-36.  x: (3,) or (3, n, m)."""
+    s = _solver_for(data[0], data[1])
+    return s.sumregs_evaluate(x, Δ, delta_t=Δt, **kwargs)
+
+
+def sumregs_denoise(data, x, op1=None, op2=None, op3=None, pOp=None, **kwargs):
+    """u = sumregs_denoise(f, x, op1, op2, op3[, pOp]) -- /root/reference/src/SumRegsLearningFunction.jl:38-85 (the
+    operators are fixed on this path: forward, backward, centred differences)."""
+    s = _solver_for(None, data)
+    return s.sumregs_denoise(x, **kwargs)
 
 
 def TVDenoise(data, parameter, **kwargs):

@@ -160,6 +160,21 @@ int bpltv_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_p
 int bpltv_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta,
                    const bpltv_params *p, double *u_out, double *cost_out, double *grad_out);
 
+/* Sum-of-regularisers model: min_u 0.5||u - f||^2 + a1 ||G_fwd u|| + a2 ||G_bwd u|| + a3 ||G_ctr u|| (isotropic
+ * 2,1 norms; forward, backward and centred differences), src/SumRegsLearningFunction.jl.
+ *   bpltv_sumregs_evaluate = sumregs_learning_function(x, data, D; Dt = 1e-3) -> (u, cost, grad)   (:8-36)
+ *   bpltv_sumregs_denoise  = sumregs_denoise(data, x, op1, op2, op3[, pOp])                       (:38-85)
+ * alpha: 3 * am * an doubles, the three parameter slices x[:, :, k] (column major am x an) one after the other;
+ * am = an = 1 is the Vector x = [a1; a2; a3] (:8), m x n x 3 the patch parameter (:22).  grad_out has the same
+ * layout.  p = NULL: bpltv_sumregs_default_params (delta_t = 1e-3).  D > delta_t: sumregs_gradient (:264-407),
+ * else sumregs_gradient_reg (:112-262; BPLTV_E_UNSUPPORTED for a patch parameter, whose row-scaled system is not
+ * symmetric).  The adjoint system has bandwidth 2M and is factored by the HBM band path for every image size.
+ * Both take single- and multi-device handles; set_data, per_image, u_device, stats are shared with the TV model. */
+int bpltv_sumregs_default_params(bpltv_params *p);
+int bpltv_sumregs_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_params *p, double *u_out);
+int bpltv_sumregs_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta, const bpltv_params *p,
+                           double *u_out, double *cost_out, double *grad_out);
+
 /* Sharded form: this handle's images only.  partial_out (host, 1 + am*an doubles) receives
  * [cost, grad...] summed over the handle's O images; the caller all-reduces it across shards
  * (cost and grad are plain sums over images: src/TVLearningFunctionVec.jl:20,80,172). */

@@ -37,9 +37,8 @@
  * (L = sqrt(8) bound on ||grad||, gamma = 1 strong convexity of the fidelity term).
  * Row k = {tau, sigma, omega, 1/(1+tau), 1+omega} used in iteration k.
  * ---------------------------------------------------------------------------------------- */
-BPLO_API void bplo_step_table(int maxiter, double tau0, double sigma0, int accel, double *tab)
+BPLO_API void bplo_step_table_L(int maxiter, double tau0, double sigma0, int accel, double L, double *tab)
 {
-    const double L = sqrt(8.0);
     double tau = tau0 / L, sigma = sigma0 / L;
     const double gamma = 1.0;
     for (int k = 0; k < maxiter; ++k) {
@@ -54,6 +53,11 @@ BPLO_API void bplo_step_table(int maxiter, double tau0, double sigma0, int accel
             sigma = sigma / omega;
         }
     }
+}
+
+BPLO_API void bplo_step_table(int maxiter, double tau0, double sigma0, int accel, double *tab)
+{
+    bplo_step_table_L(maxiter, tau0, sigma0, accel, sqrt(8.0), tab);
 }
 
 /* PatchOp: m x n parameter (column-major, am x an) -> pixel (i,j) uses x[(i*am)/M + am*((j*an)/N)].

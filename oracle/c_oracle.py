@@ -16,8 +16,8 @@ _lib = None
 
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(_HERE, "bpltv_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("bpltv_oracle.c", "sumregs_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbpltv_oracle.so"])
     return _SO
 
@@ -53,6 +53,19 @@ def lib():
                                     C.c_double, C.c_int, _dp, _dp]
         L.bplo_gradient.restype = C.c_int
         L.bplo_max_threads.restype = C.c_int
+        # sum of regularisers (sumregs_oracle.c)
+        L.bplo_sr_grad.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.bplo_sr_gradT.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.bplo_sumregs_pdhg.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, C.c_int, C.c_int, _dp, _dp, C.c_int]
+        L.bplo_sumregs_pdhg.restype = C.c_int
+        L.bplo_sumregs_gap.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        L.bplo_sumregs_gradient_image.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                  _dp, _dp, _dp]
+        L.bplo_sumregs_gradient_image.restype = C.c_int
+        L.bplo_sumregs_gradient.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                            C.c_double, C.c_int, _dp, _dp]
+        L.bplo_sumregs_gradient.restype = C.c_int
         L.bplo_rsqrt_nr.argtypes = [C.c_double]
         L.bplo_rsqrt_nr.restype = C.c_double
         _lib = L
@@ -254,6 +267,79 @@ def tv_op_learning_function(x, data, delta, delta_t=1e-6, maxiter=5000, rho=0.0,
     c = cost(u, ubar)
     g = gradient(x, u, ubar, reg=not (delta > delta_t))
     return u, c, g
+
+
+# ---------------------------------------------------------------------------------------------------
+# Sum of regularisers (oracle/sumregs_oracle.c; /root/reference/src/SumRegsLearningFunction.jl)
+# Parameter convention: the Julia Vector x = [a1; a2; a3] is a numpy array of shape (3,); the Julia m x n x 3 array
+# is a numpy array of shape (3, n, m) (C-contiguous == the three column-major m x n slices one after the other).
+# ---------------------------------------------------------------------------------------------------
+def sr_alpha_arg(alpha):
+    a = np.ascontiguousarray(alpha, dtype=np.float64)
+    if a.ndim == 1:
+        if a.shape[0] != 3:
+            raise ValueError("sum-of-regularisers parameter vector must have 3 entries")
+        return a, 1, 1
+    if a.ndim != 3 or a.shape[0] != 3:
+        raise ValueError("sum-of-regularisers parameter must have shape (3,) or (3, n, m)")
+    return a, a.shape[2], a.shape[1]
+
+
+def sr_grad(k, x):
+    x = _c(x); N, M = x.shape
+    d1 = np.empty_like(x); d2 = np.empty_like(x)
+    lib().bplo_sr_grad(k, M, N, _p(x), _p(d1), _p(d2))
+    return d1, d2
+
+
+def sr_gradT(k, y1, y2):
+    y1 = _c(y1); y2 = _c(y2); N, M = y1.shape
+    r = np.empty_like(y1)
+    lib().bplo_sr_gradT(k, M, N, _p(y1), _p(y2), _p(r))
+    return r
+
+
+def sumregs_pdhg(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True, nthreads=1, return_dual=False):
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = sr_alpha_arg(alpha)
+    x = np.empty_like(f3)
+    y = np.empty((O, 6, N, M)) if return_dual else None
+    rc = lib().bplo_sumregs_pdhg(M, N, O, _p(f3), _p(a), am, an, rho, tau0, sigma0, int(accel), maxiter, _p(x), _p(y), nthreads)
+    if rc:
+        raise RuntimeError("bplo_sumregs_pdhg rc=%d" % rc)
+    return (x.reshape(f.shape), y) if return_dual else x.reshape(f.shape)
+
+
+def sumregs_gap(u, y, f, alpha):
+    u = _c(u); y = _c(y); f = _c(f)
+    u3 = u.reshape((-1,) + u.shape[-2:])
+    O, N, M = u3.shape
+    a, am, an = sr_alpha_arg(alpha)
+    out = np.empty(O)
+    lib().bplo_sumregs_gap(M, N, O, _p(u3), _p(y), _p(f), _p(a), am, an, _p(out))
+    return out
+
+
+def sumregs_gradient(alpha, u, ubar, reg=False, kappa_cap=1e14, nref=3, per_image=False):
+    u = _c(u); ubar = _c(ubar)
+    O, N, M = u.shape
+    a, am, an = sr_alpha_arg(alpha)
+    out = np.empty(3 * am * an)
+    pi = np.empty((O, 3 * am * an))
+    rc = lib().bplo_sumregs_gradient(M, N, O, _p(u), _p(ubar), _p(a), am, an, int(reg), kappa_cap, nref, _p(out), _p(pi))
+    if rc:
+        raise RuntimeError("bplo_sumregs_gradient rc=%d" % rc)
+    g = out.copy() if (am == 1 and an == 1) else out.reshape(3, an, am)
+    return (g, pi) if per_image else g
+
+
+def sumregs_learning_function(x, data, delta, delta_t=1e-3, maxiter=5000, nthreads=1):
+    """(u, cost, grad) of /root/reference/src/SumRegsLearningFunction.jl:8-36, C restatement."""
+    ubar, f = data
+    u = sumregs_pdhg(f, x, maxiter=maxiter, nthreads=nthreads)
+    return u, cost(u, ubar), sumregs_gradient(x, u, ubar, reg=not (delta > delta_t))
 
 
 def rsqrt_nr(x):

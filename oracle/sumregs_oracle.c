@@ -111,7 +111,7 @@ BPLO_API void bplo_sr_gradT(int k, int M, int N, const double *y1, const double 
         for (int i = 0; i < M; ++i) out[i + (size_t)M * j] = sr_gradT_at(k, M, N, y1, y2, i, j);
 }
 
-#define SR_L 4.242640687119285 /* sqrt(18): ||G_1||^2 + ||G_2||^2 + ||G_3||^2 <= 8 + 8 + 2 */
+#define SR_L sqrt(18.0) /* ||G_1||^2 + ||G_2||^2 + ||G_3||^2 <= 8 + 8 + 2 */
 
 /* ---- PDHG, three duals ---------------------------------------------------------------------------- */
 static void sr_pdhg_image(int M, int N, const double *f, const double *alpha, int am, int an, const double *tab,

@@ -1,0 +1,84 @@
+"""GPU parity of the sum-of-regularisers learning function (SURVEY 8(f) rank 3;
+/root/reference/src/SumRegsLearningFunction.jl) against oracle/sumregs_oracle.c: PDHG with three duals bit-exact,
+loss to rounding, adjoint gradients (vector and patch parameter, both branches) to the stated tolerance.
+PARITY UNPINNED: the oracle's operators / recurrence are restatements of an absent package (see its header)."""
+import numpy as np
+import pytest
+from conftest import DATASETS_NPZ, synth_batch
+from oracle import np_twin as T
+
+pytestmark = pytest.mark.gpu
+
+A3 = np.array([0.03, 0.02, 0.05])
+P3 = np.stack([np.array([[0.03, 0.05], [0.02, 0.04]]), np.array([[0.02, 0.03], [0.05, 0.02]]), np.array([[0.04, 0.02], [0.03, 0.06]])])
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 33), (1, 128, 128), (3, 70, 96), (1, 20, 150)], ids=["40x33", "128", "70x96", "20x150"])
+@pytest.mark.parametrize("alpha", [A3, P3, "map"], ids=["vector", "patch22", "map"])
+def test_pdhg_bit_exact(gpu_solver_cls, oracle, shape, alpha):
+    O, N, M = shape
+    ub, f = synth_batch(O, N, M, seed=5 + M)
+    if isinstance(alpha, str):
+        alpha = 0.02 + 0.05 * np.random.default_rng(1).random((3, N, M))
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    for it, T_ in ((37, 0), (200, 3), (64, 1)):
+        u = s.sumregs_denoise(alpha, maxiter=it, tile_iters=T_)
+        assert np.array_equal(u, oracle.sumregs_pdhg(f, alpha, maxiter=it, nthreads=4)), (it, T_)
+    assert np.abs(s.sumregs_denoise(np.zeros(3), maxiter=9) - f).max() < 1e-15       # alpha = 0: u = f
+    s.close()
+
+
+@pytest.mark.parametrize("alpha", [A3, P3], ids=["vector", "patch22"])
+def test_evaluate_matches_oracle(gpu_solver_cls, oracle, alpha):
+    ub, f = synth_batch(3, 48, 40, seed=21)
+    s = gpu_solver_cls(40, 48, 3)
+    s.set_data(ub, f)
+    u, cost, grad = s.sumregs_evaluate(alpha, 0.1, maxiter=1500)
+    u0 = oracle.sumregs_pdhg(f, alpha, maxiter=1500, nthreads=4)
+    assert np.array_equal(u, u0)
+    assert np.isclose(cost, oracle.cost(u0, ub), rtol=1e-13)
+    g0 = oracle.sumregs_gradient(alpha, u0, ub)
+    assert np.shape(grad) == np.shape(g0)
+    assert np.allclose(grad, g0, rtol=1e-6, atol=1e-9 * np.abs(g0).max())
+    st = s.stats()
+    assert st["adjoint_method"] == "band-hbm" and st["reg_gradient_used"] == 0 and st["adjoint_residual"] <= 1e-8
+    rows = s.per_image()
+    assert rows.shape == (3, 1 + grad.size) and np.allclose(rows.sum(0)[1:], np.ravel(grad), rtol=1e-12)
+    if np.ndim(alpha) == 1:     # Delta <= Delta_t = 1e-3: sumregs_gradient_reg (vector parameter)
+        _, _, greg = s.sumregs_evaluate(alpha, 1e-4, maxiter=1500)
+        assert s.stats()["reg_gradient_used"] == 1
+        assert np.allclose(greg, oracle.sumregs_gradient(alpha, u0, ub, reg=True), rtol=1e-7)
+    else:
+        from bpldenoising_amd._lib import BpltvError
+        with pytest.raises(BpltvError) as e:
+            s.sumregs_evaluate(alpha, 1e-4, maxiter=50)
+        assert e.value.code == 6
+    s.close()
+
+
+def test_reference_image_and_named_entry_points(gpu_solver_cls, oracle):
+    """cameraman_128_10 through the reference-named entry points, with the drivers' start parameter
+    (/root/reference/src/BPLDenoising.jl:422-430: alpha0 = [0.001; 0.001; 0.001], Delta0 = 0.01)."""
+    import bpldenoising_amd as B
+    ub, f = T.load_dataset(DATASETS_NPZ, "cameraman_128_10")
+    x0 = np.array([0.001, 0.001, 0.001])
+    u, cost, grad = B.sumregs_learning_function(x0, (ub, f), 0.01, maxiter=2000)
+    u0 = oracle.sumregs_pdhg(f, x0, maxiter=2000)
+    assert np.array_equal(u, u0) and grad.shape == (3,)
+    assert np.allclose(grad, oracle.sumregs_gradient(x0, u0, ub), rtol=1e-6)
+    assert np.array_equal(B.sumregs_denoise(f, x0, maxiter=300), oracle.sumregs_pdhg(f, x0, maxiter=300))
+    B.learning_function.clear_cache()
+
+
+def test_sharded_handle(gpu_solver_cls):
+    ub, f = synth_batch(4, 40, 36, seed=22)
+    s1 = gpu_solver_cls(36, 40, 4)
+    s1.set_data(ub, f)
+    u0, c0, g0 = s1.sumregs_evaluate(A3, 0.1, maxiter=400)
+    s1.close()
+    s = gpu_solver_cls(36, 40, 4, devices=[0, 0])
+    s.set_data(ub, f)
+    u, c, g = s.sumregs_evaluate(A3, 0.1, maxiter=400, deterministic=1)
+    assert np.array_equal(u, u0) and c == c0 and np.array_equal(g, g0)
+    s.close()
