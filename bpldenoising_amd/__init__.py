@@ -10,8 +10,10 @@ from .sharding import ShardedLearningFunction, shard_range
 from .datasets import testdataset, load_filelist_dataset
 from . import trbox
 from . import experiments
-from .experiments import scalar_bilevel_tv_learn, patch_bilevel_tv_learn
+from .experiments import (scalar_bilevel_tv_learn, patch_bilevel_tv_learn, scalar_bilevel_sumregs_learn,
+                          patch_bilevel_sumregs_learn, validate_sumregs_parameter)
 
 __all__ = ["FwdGradientOp", "L2CostFunction", "TVDenoise", "TVSolver", "denoise",
            "tv_op_learning_function", "sumregs_learning_function", "sumregs_denoise", "generate_cost", "ShardedLearningFunction", "shard_range", "testdataset",
-           "load_filelist_dataset", "trbox", "experiments", "scalar_bilevel_tv_learn", "patch_bilevel_tv_learn"]
+           "load_filelist_dataset", "trbox", "experiments", "scalar_bilevel_tv_learn", "patch_bilevel_tv_learn",
+           "scalar_bilevel_sumregs_learn", "patch_bilevel_sumregs_learn", "validate_sumregs_parameter"]

@@ -210,10 +210,11 @@ __device__ __forceinline__ void hb2_mma_chunk(const double* __restrict__ As, con
     }
 }
 
-// P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k).  grid (ceil(bw/64) * 2 * nprob), id = tile * nprob + problem; block BG_T.
+// P(rrel, c) = sum_k A(k0+128+rrel, k0+k) Linv11(c, k)   (full != 0: Linv11 is a full matrix -- the LU path passes
+// the transposed inverse of the diagonal block, so that P = A21 A11^-1).  grid (ceil(bw/64) * 2 * nprob), id = tile * nprob + problem; block BG_T.
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void hb2_trsm_kernel(const double* __restrict__ band, int bw, int n, int k0,
                                                         int npanel, const double* __restrict__ Linv,
-                                                        double* __restrict__ P, int bwp, int nprob) {
+                                                        double* __restrict__ P, int bwp, int nprob, int full) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
     const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
     BgAcc acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
-    const int nchunk = (c0 + 64) / BG_KC;   // Linv11(c, k) = 0 for k > c
+    const int nchunk = full ? HB2_NB / BG_KC : (c0 + 64) / BG_KC;   // Cholesky: Linv11(c, k) = 0 for k > c
     double va[8], vb[8];
     hb2_fetch_band(Bi, W, bw, n, R0, k0, tid, va);
     hb2_fetch_dense(Li, HB2_NB, HB2_NB, HB2_NB, c0, 0, tid, vb);
@@ -278,12 +279,14 @@ __host__ __device__ inline int hb2_update_tiles(int nt, int part) {
 }
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int bw, int n, int k0,
                                                           const double* __restrict__ L11, const double* __restrict__ P,
-                                                          int bwp, int part, int nprob) {
+                                                          int bwp, int part, int nprob, const double* __restrict__ PB = nullptr) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
     const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
     double* Bi = band + (size_t)img * n * W;
     const double* Pi = P + (size_t)img * bwp * HB2_NB;
+    // LU path: A(R, C) -= sum_k PA(R, k) PB(C, k) with two different panels (L21 and U12^T); Cholesky: PB = PA
+    const double* Pj = PB ? PB + (size_t)img * bwp * HB2_NB : Pi;
     const int nt = (bw + 63) / 64;
     const int bx = (int)(blockIdx.x / (unsigned)nprob), gx = (int)(gridDim.x / (unsigned)nprob);
     int ta = -1, tb = -1;   // tile of this workgroup (none: copies only)
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
         int t = bx; ta = 0;
         while (t > ta) { t -= ta + 1; ++ta; }
         tb = t;
-    } else if (part == 1) {
+    } else if (part == 1 || part == 3) {   // 3: the tiles of part 1 without the copies (LU path, upper band)
         const int nA0 = nt > 2 ? nt - 2 : 0;
         if (bx < nA0) { ta = 2 + bx; tb = 0; }
         else if (bx < 2 * nA0) { ta = 2 + bx - nA0; tb = 1; }
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
     if (part == 1) {
         for (int item = bx; item < 1 + nt; item += gx) {
             if (item == 0) {
+                if (!L11) continue;   // LU path: the diagonal block of L is the identity
                 const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
                 for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
                     double v[16];
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
     for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
     double va[8], vb[8];
     hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, 0, tid, va);
-    hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * tb, 0, tid, vb);
+    hb2_fetch_dense(Pj, bwp, bwp, HB2_NB, 64 * tb, 0, tid, vb);
     constexpr int nchunk = HB2_NB / BG_KC;
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
         __syncthreads();
         if (ch + 1 < nchunk) {
             hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, (ch + 1) * BG_KC, tid, va);
-            hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * tb, (ch + 1) * BG_KC, tid, vb);
+            hb2_fetch_dense(Pj, bwp, bwp, HB2_NB, 64 * tb, (ch + 1) * BG_KC, tid, vb);
         }
         hb2_mma_chunk(As, Bs, acc);
     }
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 // grid (1 + ceil(bw/128), O), block BS_T.
 __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict__ band, const double* __restrict__ Linv,
                                                        int bw, int n, int k0, int npanel, double* __restrict__ x,
-                                                       double* __restrict__ y) {
+                                                       double* __restrict__ y, int unit_diag = 0) {
     __shared__ double v[HB2_NB], yb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
     const int W = bw + 1;
@@ -407,9 +411,14 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
     double* xv = x + (size_t)img * n;
     if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? xv[k0 + tid] : 0.0;
     __syncthreads();
-    double s0 = 0.0, s1 = 0.0;
-    bcr_mv_partial(Linv + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, 1, s0, s1);
-    const double val = bcr_mv_reduce(red, HB2_NB, s0, s1);
+    double val;
+    if (unit_diag) {   // LU path: the diagonal block of L is the identity
+        val = (tid < HB2_NB) ? v[tid] : 0.0;
+    } else {
+        double s0 = 0.0, s1 = 0.0;
+        bcr_mv_partial(Linv + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, 1, s0, s1);
+        val = bcr_mv_reduce(red, HB2_NB, s0, s1);
+    }
     if (blockIdx.x == 0) {
         if (tid < HB2_NB && k0 + tid < n) y[(size_t)img * n + k0 + tid] = val;
         return;
@@ -444,9 +453,12 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
 
 // apply_only (twisted solve): block k0 lies in the trailing window of a partially factored problem; its
 // solution is already in `x` (the middle block's), only the earlier equations are updated.
+// mvmode: 2 = `LinvT` is upper triangular (Cholesky); 0 = a full matrix (LU path: the inverse of the diagonal block
+// of U, with `band` = the upper band stored by rows).
 __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict__ band, const double* __restrict__ LinvT,
                                                        int bw, int n, int k0, int npanel, double* __restrict__ y,
-                                                       double* __restrict__ x, double* __restrict__ acc, int apply_only) {
+                                                       double* __restrict__ x, double* __restrict__ acc, int apply_only,
+                                                       int mvmode = 2) {
     __shared__ double v[HB2_NB], xb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
     const int W = bw + 1;
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
         if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? yv[k0 + tid] : 0.0;
         __syncthreads();
         double s0 = 0.0, s1 = 0.0;
-        bcr_mv_partial(LinvT + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, 2, s0, s1);
+        bcr_mv_partial(LinvT + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB, HB2_NB, v, mvmode, s0, s1);
         const double val = bcr_mv_reduce(red, HB2_NB, s0, s1);
         if (blockIdx.x == 0) {
             if (tid < HB2_NB && k0 + tid < n) {

@@ -18,6 +18,7 @@
 #include "../../include/bpltv.h"
 #include "adjoint_hbm_kernels.hpp"
 #include "hb_band_solver.hpp"
+#include "hb_lu_solver.hpp"
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
@@ -160,6 +161,9 @@ struct bpltv_handle {
     bool last_is_sr = false;                        // the last solve was the sum-of-regularisers model
     double *d_srcoef = nullptr, *d_srdiag = nullptr, *d_srw = nullptr, *d_srgpix = nullptr;
     HbBandSolver hb_sr;
+    HbLuSolver lu_sr;             // non-symmetric row-scaled system of sumregs_gradient_reg with a patch parameter
+    bool lu_sr_ready = false;
+    double* d_srdiagU = nullptr;  // its upper diagonals (7 planes)
     std::map<SrGraphKey, hipGraphExec_t> sr_graphs;
     bpltv_stats_t st;
     std::string err;
@@ -1138,8 +1142,27 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
     const size_t tot = h->tot, P = (size_t)am * an;
     const int patch = !(am == 1 && an == 1);
-    if (reg && patch)
-        return set_err(h, BPLTV_E_UNSUPPORTED, "sumregs_gradient_reg with a patch parameter (SumRegsLearningFunction.jl:195-262) row-scales three operators differently: the system is not symmetric and has no GPU factorisation here yet");
+    // sumregs_gradient_reg with a patch parameter (SumRegsLearningFunction.jl:250) scales the ROWS of the three terms
+    // with three different maps: not symmetric -> banded LU (hb_lu_solver.hpp) instead of the Cholesky path
+    const char* force_lu = getenv("BPLTV_SR_FORCE_LU");   // test aid: the LU path on the symmetric systems too
+    const bool rowsc = reg && patch;
+    const bool lu = rowsc || (force_lu && force_lu[0] == '1');
+    if (lu) {
+        if (rowsc && !(h->alpha_min > 0.0))
+            return set_err(h, BPLTV_E_ARG, "sumregs_gradient_reg with a patch parameter needs every entry > 0 (min = %g)", h->alpha_min);
+        if (!h->lu_sr_ready) {
+            const int n = (int)h->npx, bw = std::min(2 * M, n - 1);
+            size_t freeb = 0, totalb = 0;
+            (void)hipMemGetInfo(&freeb, &totalb);
+            const size_t need = h->lu_sr.bytes_needed(bw, n, O) + 7 * tot * sizeof(double);
+            if (need + (2ull << 30) > freeb)
+                return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint (banded LU): %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
+            HIPCHK(h, hipMalloc((void**)&h->d_srdiagU, 7 * tot * sizeof(double)));
+            const int rc2 = h->lu_sr.alloc(bw, n, O, h->stream);
+            if (rc2) return set_err(h, rc2, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
+            h->lu_sr_ready = true;
+        }
+    }
     double kact = 1.0 / 2.220446049250313e-16;   // eps() in the vector AND the patch variant (:319, :389)
     const double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
     if (kact > kcap) kact = kcap;
@@ -1153,22 +1176,36 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(sr_adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N, O, patch, reg,
                        kact, C);
-    hipLaunchKernelGGL(sr_adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_srdiag);
+    const double* rowscale = rowsc ? h->d_alpha : nullptr;
+    if (lu) HIPCHK(h, hipMemsetAsync(h->d_srdiagU, 0, 7 * tot * sizeof(double), h->stream));
+    hipLaunchKernelGGL(sr_adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_srdiag, rowscale, am, an,
+                       lu ? h->d_srdiagU : (double*)nullptr);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
     BandDiags D;
     D.planes = h->d_srdiag; D.tot = tot; D.nd = 7;
     D.off[0] = 0; D.off[1] = 1; D.off[2] = 2; D.off[3] = M - 1; D.off[4] = M; D.off[5] = M + 1; D.off[6] = 2 * M;
-    rc = h->hb_sr.factor(D, h->d_fail);
-    if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    if (lu) {
+        BandDiags DU = D;
+        DU.planes = h->d_srdiagU;
+        rc = h->lu_sr.factor(D, DU, h->d_fail);
+        if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
+    } else {
+        rc = h->hb_sr.factor(D, h->d_fail);
+        if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    }
     auto residual = [&](double* out) {
         hipLaunchKernelGGL(sr_adj_flux_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_srw);
-        hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, h->d_srw, M, N, O, out);
+        hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, h->d_srw, M, N, O, out, rowscale,
+                           am, an);
+    };
+    auto solve = [&](double* v, double* acc) {
+        if (lu) h->lu_sr.solve(v, acc, h->d_gpix); else h->hb_sr.solve(v, acc, h->d_gpix);
     };
     HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->hb_sr.solve(h->d_p, nullptr, h->d_gpix);
+    solve(h->d_p, nullptr);
     for (int it = 0; it < nref; ++it) {
         residual(h->d_r);
-        h->hb_sr.solve(h->d_r, h->d_p, h->d_gpix);
+        solve(h->d_r, h->d_p);
     }
     residual(h->d_r);
     hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_srdiag, (int)h->npx, h->d_resn);
@@ -1680,6 +1717,8 @@ int bpltv_destroy(bpltv_t* h) {
         if (e) (void)hipEventDestroy(e);
     h->hb.release();
     h->hb_sr.release();
+    h->lu_sr.release();
+    if (h->d_srdiagU) (void)hipFree(h->d_srdiagU);
     for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* q : {(void*)h->d_srcoef, (void*)h->d_srdiag, (void*)h->d_srw, (void*)h->d_srgpix})
         if (q) (void)hipFree(q);

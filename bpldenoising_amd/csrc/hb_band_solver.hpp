@@ -161,16 +161,16 @@ struct HbBandSolver {
             part1_pending = false;
             if (k0 + HB2_NB < nrow)
                 hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, hb.npanel, hb.Linv, Pp,
-                                   bwp, nprob);
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, Pp, bwp, 0, nprob);
+                                   bwp, nprob, 0);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, Pp, bwp, 0, nprob, (const double*)nullptr);
             if (!single_stream) {
                 HBCHK(hipEventRecord(ev[0], stream));
                 HBCHK(hipStreamWaitEvent(s2, ev[0], 0));
             }
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 1, nprob);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 1, nprob, (const double*)nullptr);
             if (!single_stream) HBCHK(hipEventRecord(ev[1], s2));
             part1_pending = true;
-            if (g2 > 0) hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 2, nprob);
+            if (g2 > 0) hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 2, nprob, (const double*)nullptr);
         }
         if (!single_stream) {   // join: everything on the second stream is complete before the caller continues
             HBCHK(hipEventRecord(ev[1], s2));
@@ -206,17 +206,17 @@ struct HbBandSolver {
     void fwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* x, double* y) {
         const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
         for (int k0 = 0; k0 < nelim; k0 += HB2_NB)
-            hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.Linv, bw, nrow, k0, hb.npanel, x, y);
+            hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.Linv, bw, nrow, k0, hb.npanel, x, y, 0);
     }
     void bwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* y, double* x, double* acc) {
         const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
         // rows of the trailing window (partial factorisation): their solution is given, push it to the earlier rows
         for (int k0 = ((nrow - 1) / HB2_NB) * HB2_NB; k0 >= nelim; k0 -= HB2_NB)
             hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x,
-                               (double*)nullptr, 1);
+                               (double*)nullptr, 1, 2);
         for (int k0 = ((nelim - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
             hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x, acc,
-                               0);
+                               0, 2);
     }
 
     // v <- A^-1 v, accv += solution (accv may be null).  scratch: [O][n] doubles (not twisted: holds y).

@@ -211,6 +211,7 @@ __device__ __forceinline__ double sr_gradT_at(int k, const double* __restrict__ 
 __global__ __launch_bounds__(256) void sr_adj_setup_kernel(const double* __restrict__ u, const double* __restrict__ ubar,
                                                            const double* __restrict__ alpha, int am, int an, int M, int N, int O,
                                                            int patch, int reg, double kappa_act, SrCoef C) {
+    // reg && patch: the parameter scales ROWS of term k (SumRegsLearningFunction.jl:250) and stays out of c, kap
     const size_t npx = (size_t)M * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= npx * O) return;
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(256) void sr_adj_setup_kernel(const double* __restr
         } else {
             if (ng > 1.0 / gamma) {
                 t1 = -g2 / ng; t2 = g1 / ng;
-                c = a / ng;
+                c = patch ? 1.0 / ng : a / ng;
                 h1 = g1 / ng; h2 = g2 / ng;
             } else {
-                kap = a * gamma;
+                kap = patch ? gamma : a * gamma;
                 h1 = gamma * g1; h2 = gamma * g2;
             }
         }
@@ -282,13 +283,20 @@ __device__ __forceinline__ int sr_diag_slot(int d, int M) {
     if (d == 2 * M) return 6;
     return -1;
 }
-__global__ __launch_bounds__(256) void sr_adj_assemble_kernel(SrCoef C, int M, int N, int O, double* __restrict__ planes) {
+// rowscale (nullable; with am, an: the parameter array) and planesU (nullable, zero-initialised by the caller): the
+// non-symmetric row-scaled system of sumregs_gradient_reg with a patch parameter -- every entry A(r, q) of term k is
+// multiplied by x_k at pixel r, and the strictly upper entries A(q - off, q) go to planesU[t][q - off] (by rows).
+__global__ __launch_bounds__(256) void sr_adj_assemble_kernel(SrCoef C, int M, int N, int O, double* __restrict__ planes,
+                                                              const double* __restrict__ rowscale, int am, int an,
+                                                              double* __restrict__ planesU) {
     const size_t npx = (size_t)M * N;
     const size_t col = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= npx * O) return;
     const int img = (int)(col / npx), q = (int)(col - (size_t)img * npx);
     const int i = q % M, j = q / M;
     double acc[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double accu[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const size_t astride = (size_t)am * an;
     const size_t ib = (size_t)img * npx;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -314,17 +322,24 @@ __global__ __launch_bounds__(256) void sr_adj_assemble_kernel(SrCoef C, int M, i
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int d = node[a] - q;
-                    if (d < 0) continue;
+                    if (d < 0 && !planesU) continue;
                     const double ta = t1 * v1[a] + t2 * v2[a];
-                    const double val = c * ta * tb + kp * (v1[a] * v1[b] + v2[a] * v2[b]);
-                    const int sl = sr_diag_slot(d, M);
-                    if (sl >= 0) acc[sl] += val;
+                    double val = c * ta * tb + kp * (v1[a] * v1[b] + v2[a] * v2[b]);
+                    if (rowscale) val *= rowscale[k * astride + sr_alpha_index(am, an, M, N, node[a] % M, node[a] / M)];
+                    const int sl = sr_diag_slot(d < 0 ? -d : d, M);
+                    if (sl >= 0) { if (d >= 0) acc[sl] += val; else accu[sl] += val; }
                 }
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < 7; ++t) planes[(size_t)t * C.tot + col] = acc[t];
+    if (planesU) {
+        const int off[7] = {0, 1, 2, M - 1, M, M + 1, 2 * M};
+#pragma unroll
+        for (int t = 1; t < 7; ++t)
+            if (q - off[t] >= 0 && sr_diag_slot(off[t], M) == t) planesU[(size_t)t * C.tot + ib + (q - off[t])] = accu[t];
+    }
 }
 
 // residual, pass 1: w_k = W_k (G_k p) per element -> w[(2k + c) * tot + e]
@@ -350,7 +365,8 @@ __global__ __launch_bounds__(256) void sr_adj_flux_kernel(SrCoef C, const double
 
 // residual, pass 2: out = rhs - (p + sum_k G_k^T w_k)
 __global__ __launch_bounds__(256) void sr_adj_residual_kernel(SrCoef C, const double* __restrict__ p, const double* __restrict__ w,
-                                                              int M, int N, int O, double* __restrict__ out) {
+                                                              int M, int N, int O, double* __restrict__ out,
+                                                              const double* __restrict__ rowscale, int am, int an) {
     const size_t npx = (size_t)M * N;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= npx * O) return;
@@ -358,9 +374,12 @@ __global__ __launch_bounds__(256) void sr_adj_residual_kernel(SrCoef C, const do
     const int i = k0 % M, j = k0 / M;
     const size_t ib = (size_t)img * npx;
     double s = p[e];
+    const size_t ai = rowscale ? sr_alpha_index(am, an, M, N, i, j) : 0, astride = (size_t)am * an;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        s += sr_gradT_at(k, w + (size_t)(2 * k) * C.tot + ib, w + (size_t)(2 * k + 1) * C.tot + ib, M, N, i, j);
+    for (int k = 0; k < 3; ++k) {
+        const double g = sr_gradT_at(k, w + (size_t)(2 * k) * C.tot + ib, w + (size_t)(2 * k + 1) * C.tot + ib, M, N, i, j);
+        s += rowscale ? rowscale[k * astride + ai] * g : g;
+    }
     out[e] = C.rhs[e] - s;
 }
 

@@ -4,6 +4,8 @@ learning function, mirroring the reference's entry points:
   scalar_bilevel_tv_learn(dataset_name=..., num_samples=...)   /root/reference/src/BPLDenoising.jl:325-343
   patch_bilevel_tv_learn(dataset_name=..., num_samples=...)    :360-377
   save_results(params, b, b_data, x, opt_img, log)             :182-297
+  scalar_bilevel_sumregs_learn / patch_bilevel_sumregs_learn   :422-489   (sum-of-regularisers model)
+  validate_sumregs_parameter                                   :506-539
 
 Written files (same names and columns as the reference):
   <prefix>.txt           performance log: iter, time, function_value, gradient_value, radius_value,
@@ -15,8 +17,8 @@ Written files (same names and columns as the reference):
 PARITY UNPINNED: `write_log` (AlgTools) and `assess_ssim` / `assess_psnr` (ImageQualityIndexes.jl) are
 external and absent; the log layout is tab separated with a header row, PSNR is 10 log10(1/MSE) for
 images in [0, 1] and SSIM is the standard Wang et al. index (11x11 Gaussian window, sigma 1.5, K = (0.01,
-0.03), mean over the map).  The reference's quirk `mean_psnr += mean_psnr` (:282, sum-of-regularisers
-variant only) is not on this path.
+0.03), mean over the map).  The reference's quirk `mean_psnr += mean_psnr` (:282, the save_results method for
+m x n x 3 parameters: the mean PSNR it writes is always 0) is reproduced for that method only.
 """
 import os
 import time
@@ -31,6 +33,10 @@ default_params = dict(verbose_iter=1, maxiter=20, save_results=True, dataset_nam
                       save_iterations=False, tol=1e-5, num_samples=1)
 bilevel_params = dict(eta1=0.25, eta2=0.75, beta1=0.25, beta2=1.9, delta0=0.1, alpha0=0.1)
 patch_bilevel_params = dict(eta1=0.25, eta2=0.75, beta1=0.25, beta2=1.9, delta0=1e-4, alpha0=1e-4 * np.ones((2, 2)))
+sumregs_bilevel_params = dict(eta1=0.25, eta2=0.75, beta1=0.25, beta2=1.9, delta0=0.01,
+                              alpha0=np.array([0.001, 0.001, 0.001]))                      # :422-430
+patch_sumregs_bilevel_params = dict(eta1=0.25, eta2=0.75, beta1=0.25, beta2=1.5, delta0=0.1,
+                                    alpha0=0.001 * np.ones((3, 2, 2)))                     # :455-462, Julia ones(2,2,3)
 default_save_prefix = "results"
 
 _ALIASES = {"η₁": "eta1", "η₂": "eta2", "β₁": "beta1", "β₂": "beta2", "Δ₀": "delta0", "α₀": "alpha0"}
@@ -102,7 +108,8 @@ def save_results(params, b, b_data, x, opt_img, log, out_root=None):
             ns, npsnr = assess_ssim(b[i], b_data[i]), assess_psnr(b[i], b_data[i])
             os_, opsnr = assess_ssim(b[i], opt_img[i]), assess_psnr(b[i], opt_img[i])
             io.write("%d\t %r \t %r \t %r \t %r\n" % (i + 1, float(ns), float(npsnr), float(os_), float(opsnr)))
-            mean_ssim += os_; mean_psnr += opsnr
+            mean_ssim += os_
+            mean_psnr += mean_psnr if np.ndim(x) == 3 else opsnr     # :282 (`mean_psnr += mean_psnr`) vs :203, :243
             for tag, arr in (("true", b[i]), ("data", b_data[i]), ("reco", opt_img[i])):
                 p = "%s_%s_%d.png" % (prefix, tag, i + 1)
                 _save_png(p, arr); written["png"].append(p)
@@ -111,6 +118,11 @@ def save_results(params, b, b_data, x, opt_img, log, out_root=None):
         p = prefix + "_par.png"
         _save_png(p, linear_stretch(patch_upsample(x, b.shape[2], b.shape[1])))
         written["png"].append(p)
+    elif np.ndim(x) == 3:                          # :290-296: one histogram stretch over the three upsampled slices
+        xb = linear_stretch(np.stack([patch_upsample(x[k], b.shape[2], b.shape[1]) for k in range(3)]))
+        for k in range(3):
+            p = "%s_par_%d.png" % (prefix, k + 1)
+            _save_png(p, xb[k]); written["png"].append(p)
     return written
 
 
@@ -162,6 +174,48 @@ def patch_bilevel_tv_learn(learning_function=None, datasets_root=None, npz=None,
     b, b_noisy, x, u, log = _run(params, learning_function, datasets_root, npz, out_root, lf_kwargs)
     u = linear_stretch(u)                                                               # :371
     return x, u, log, save_results(params, b, b_noisy, x, u, log, out_root)
+
+
+def scalar_bilevel_sumregs_learn(learning_function=None, datasets_root=None, npz=None, out_root=None, lf_kwargs=None, **kwargs):
+    """/root/reference/src/BPLDenoising.jl:432-449: x in R^3 (forward, backward, centred TV weights)."""
+    if learning_function is None:
+        from .learning_function import sumregs_learning_function as learning_function
+    params = _resolve(sumregs_bilevel_params, kwargs)
+    params["save_prefix"] = "sumregs_optimal_parameter_scalar_" + params["dataset_name"]
+    b, b_noisy, x, u, log = _run(params, learning_function, datasets_root, npz, out_root, lf_kwargs)
+    u = linear_stretch(u)                                                               # :444
+    return x, u, log, save_results(params, b, b_noisy, x, u, log, out_root)
+
+
+def patch_bilevel_sumregs_learn(learning_function=None, datasets_root=None, npz=None, out_root=None, lf_kwargs=None, **kwargs):
+    """/root/reference/src/BPLDenoising.jl:464-481: x of shape m x n x 3 (numpy (3, n, m))."""
+    if learning_function is None:
+        from .learning_function import sumregs_learning_function as learning_function
+    params = _resolve(patch_sumregs_bilevel_params, kwargs)
+    shp = np.shape(params["alpha0"])
+    params["save_prefix"] = "sumregs_optimal_parameter_patch_%s%s" % ((shp[2], shp[1], shp[0]), params["dataset_name"])
+    b, b_noisy, x, u, log = _run(params, learning_function, datasets_root, npz, out_root, lf_kwargs)
+    u = linear_stretch(u)                                                               # :476
+    return x, u, log, save_results(params, b, b_noisy, x, u, log, out_root)
+
+
+def validate_sumregs_parameter(parameter, dataset_name="cameraman_128_5", datasets_root=None, npz=None, out_root=None,
+                               learning_function=None, **solver_kwargs):
+    """/root/reference/src/BPLDenoising.jl:506-539 as written there calls `sumregs_learning_function(parameter,
+    noisy, 0.1)` with the noisy batch in the place of the (true, noisy) tuple -- which cannot index `data[2]` as
+    intended; the evident intent (denoise the validation set with the learned parameter, report cost and quality)
+    is what is implemented.  Returns (u, cost, written)."""
+    if learning_function is None:
+        from .learning_function import sumregs_learning_function as learning_function
+    full = _full(dataset_name)
+    img, noisy = _dataset(dataset_name, None, datasets_root, npz)
+    u, cost, _ = learning_function(np.asarray(parameter, dtype=np.float64), (img, noisy), 0.1, **solver_kwargs)
+    u = np.asarray(u)
+    params = dict(save_results=True, dataset_name=full,
+                  save_prefix="val_sumregs_optimal_parameter_scalar_%s_%s" % (tuple(np.shape(parameter)[::-1]), full))
+    written = save_results(params, img, noisy, 0.0, u, [], out_root)
+    os.remove(written.pop("perf"))
+    return u, cost, written
 
 
 # ---- forward-only sweeps and validation (SURVEY 8f rank 4; src/BPLDenoising.jl:92-178, 381-415) ----------

@@ -167,8 +167,8 @@ int bpltv_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta
  * alpha: 3 * am * an doubles, the three parameter slices x[:, :, k] (column major am x an) one after the other;
  * am = an = 1 is the Vector x = [a1; a2; a3] (:8), m x n x 3 the patch parameter (:22).  grad_out has the same
  * layout.  p = NULL: bpltv_sumregs_default_params (delta_t = 1e-3).  D > delta_t: sumregs_gradient (:264-407),
- * else sumregs_gradient_reg (:112-262; BPLTV_E_UNSUPPORTED for a patch parameter, whose row-scaled system is not
- * symmetric).  The adjoint system has bandwidth 2M and is factored by the HBM band path for every image size.
+ * else sumregs_gradient_reg (:112-262; with a patch parameter its row-scaled system is not symmetric and is
+ * factored by a banded LU).  The adjoint system has bandwidth 2M and is factored in HBM for every image size.
  * Both take single- and multi-device handles; set_data, per_image, u_device, stats are shared with the TV model. */
 int bpltv_sumregs_default_params(bpltv_params *p);
 int bpltv_sumregs_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_params *p, double *u_out);

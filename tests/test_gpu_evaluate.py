@@ -442,6 +442,17 @@ def test_bcr_kernel_unit_checks(gpu_solver_cls):
     assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 
+def test_band_solver_unit_checks(gpu_solver_cls):
+    """tools/lu_unit.hip: the HBM band solvers (banded Cholesky plain and twisted, block LU without pivoting) on
+    random band matrices against dense host elimination, incl. the diagonal sets of the sum-of-regularisers model."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "_bin", "lu_unit")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+
+
 def test_full_size_gradient_properties_1024(gpu_solver_cls):
     """BASELINE config 5 image size (1024 x 1024, HBM-resident band, 8.6 GB factor): properties that need
     no oracle run -- the refined adjoint solve reaches the residual level of the 128^2 cases, the
