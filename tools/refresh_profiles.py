@@ -119,9 +119,12 @@ def publish(tag):
             lines = [l for l in open(p) if l.startswith("{")]
             if lines:
                 open(os.path.join(PRO, "%s_%s.json" % (tag, name)), "w").write(lines[-1]); copied.append(name)
-    p = os.path.join(SRC, "eval_cfg5.log")
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(PRO, "%s_eval_cfg5.log" % tag)); copied.append("eval_cfg5.log")
+    for log in ("eval_cfg5.log", "sumregs_time.log"):
+        p = os.path.join(SRC, log)
+        if os.path.exists(p):
+            with open(os.path.join(PRO, "%s_%s" % (tag, log)), "w") as fh:
+                fh.writelines(l for l in open(p) if "amdgpu.ids" not in l)
+            copied.append(log)
     # traffic.json: per workload, HBM-side bytes and VALU wave-instructions of one pdhg_tile_kernel launch
     tf = os.path.join(PRO, "traffic.json")
     tj = {"workloads": {}}
