@@ -4,7 +4,7 @@
 # NOT EXECUTED HERE: Julia is not available in the build image; the same entry points are exercised through
 # bpldenoising_amd/_lib.py (ctypes) by the test suite.
 # Same exports as src/TVLearningFunctionVec.jl:6
-export tv_op_learning_function, denoise
+export tv_op_learning_function, denoise, sumregs_learning_function
 
 const libbpltv = "libbpltv"            # on LD_LIBRARY_PATH, or an absolute path
 
@@ -119,3 +119,22 @@ end
 
 # src/BPLDenoising.jl:41-82
 TVDenoise(data, parameter; visualize = false) = denoise(data, parameter, FwdGradientOp(); maxiter = 10000)
+
+# src/SumRegsLearningFunction.jl:8-36 -- x::Vector (3 weights: forward, backward, centred TV) or x::Array{T,3} (m x n x 3).
+# The C ABI takes the three slices one after the other, which is exactly Julia's column-major memory of x.
+function sumregs_learning_function(x::Union{AbstractVector{Float64},AbstractArray{Float64,3}}, data, Δ; Δt = 1e-3)
+    ū, f = data[1], data[2]
+    h = handle_for(ū, f)
+    a = Array{Float64}(x)
+    am, an = x isa AbstractVector ? (1, 1) : (size(x, 1), size(x, 2))
+    u = similar(f); cost = Ref{Cdouble}(0); grad = zeros(size(a))
+    r = Ref{BpltvParams}()
+    ccall((:bpltv_sumregs_default_params, libbpltv), Cint, (Ref{BpltvParams},), r)
+    d = r[]
+    p = Ref(BpltvParams(d.rho, d.tau0, d.sigma0, d.accel, d.maxiter, Δt, d.check_every, d.gap_tol, d.tile_iters,
+                        d.use_graph, d.kappa_cap, d.refine, BPLTV_DETERMINISTIC, d.reserved))
+    GC.@preserve a u grad bpltv_check(h, ccall((:bpltv_sumregs_evaluate, libbpltv), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ref{BpltvParams}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}),
+        h.ptr, a, am, an, Δ, p, u, cost, grad))
+    return u, cost[], grad
+end
