@@ -62,6 +62,26 @@ __global__ __launch_bounds__(256) void hb_init_kernel(BandDiags D, int bw, int n
     }
 }
 
+// The same on a band that is already zero: only the nd diagonals of every column.  grid (nblocks, O * sides).
+__global__ __launch_bounds__(256) void hb_init_diag_kernel(BandDiags D, int bw, int n, int sides, int np,
+                                                           double* __restrict__ band) {
+    const int W = bw + 1;
+    const int p = blockIdx.y, img = p / sides, side = p - img * sides;
+    const size_t ib = (size_t)img * n;
+    double* Bp = band + (size_t)p * np * W;
+    for (size_t col = (size_t)blockIdx.x * 256 + threadIdx.x; col < (size_t)np; col += (size_t)gridDim.x * 256) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t >= D.nd) break;
+            const int d = D.off[t];
+            bool dup = false;   // coinciding offsets (tiny M): band_entry already adds them; write once
+            for (int t2 = 0; t2 < t; ++t2) dup |= D.off[t2] == d;
+            if (dup || d > bw || (long)col + d >= np) continue;
+            Bp[col * W + d] = (side == 0) ? band_entry(D, ib, n, (long)col, d) : band_entry(D, ib, n, (long)n - 1 - (long)col - d, d);
+        }
+    }
+}
+
 // Middle block of the twisted factorisation: S = A_mid - (A_mid - S_top) - (A_mid - S_bot) with the two side
 // problems' trailing windows.  mid[img][nm][W] (a banded problem of nm rows, bandwidth min(bw, nm-1)).
 __global__ __launch_bounds__(256) void hb_mid_gather_kernel(BandDiags D, int bw, int n, int m, int nm, int np,
@@ -410,6 +430,17 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
     const double* Bi = band + (size_t)img * n * W;
     double* xv = x + (size_t)img * n;
     if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? xv[k0 + tid] : 0.0;
+    // this workgroup's 128 x 128 tile of L is requested BEFORE the diagonal-block product: its addresses do not
+    // depend on the solution, so its memory latency overlaps with that of the 128 KB inverse block
+    const int rr = tid & 127, part = tid >> 7;
+    const int R = k0 + HB2_NB + ((int)blockIdx.x - 1) * HB2_NB + rr;
+    const bool upd = blockIdx.x > 0 && R < n && R <= k0 + HB2_NB - 1 + bw;
+    double lt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * part + i, d0 = R - (k0 + c);
+        lt[i] = (upd && d0 <= bw) ? Bi[(size_t)(k0 + c) * W + d0] : 0.0;
+    }
     __syncthreads();
     double val;
     if (unit_diag) {   // LU path: the diagonal block of L is the identity
@@ -425,25 +456,20 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
     }
     if (tid < HB2_NB) yb[tid] = val;
     __syncthreads();
-    const int rr = tid & 127, part = tid >> 7;
-    const int R = k0 + HB2_NB + (blockIdx.x - 1) * HB2_NB + rr;
     double s = 0.0;
-    if (R < n && R <= k0 + HB2_NB - 1 + bw) {
+    if (upd) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int c = 16 * part + i;
-            const int d0 = R - (k0 + c), d1 = d0 - 1;
-            const double l0 = (d0 <= bw) ? Bi[(size_t)(k0 + c) * W + d0] : 0.0;
-            const double l1 = (d1 <= bw) ? Bi[(size_t)(k0 + c + 1) * W + d1] : 0.0;
-            a0 = __builtin_fma(l0, yb[c], a0);
-            a1 = __builtin_fma(l1, yb[c + 1], a1);
+            a0 = __builtin_fma(lt[i], yb[c], a0);
+            a1 = __builtin_fma(lt[i + 1], yb[c + 1], a1);
         }
         s = a0 + a1;
     }
     red[part * BS_MP + rr] = s;
     __syncthreads();
-    if (tid < HB2_NB && R < n && R <= k0 + HB2_NB - 1 + bw) {
+    if (tid < HB2_NB && upd) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q * BS_MP + tid];
@@ -465,6 +491,30 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
     const int img = blockIdx.y, tid = threadIdx.x;
     const double* Bi = band + (size_t)img * n * W;
     double* yv = y + (size_t)img * n;
+    // this workgroup's rows of L^T (earlier equation k: y_k -= sum_c L[k0+c][k] x_{k0+c}, L[k0+c][k] = band[k*W + (k0+c-k)])
+    // are requested BEFORE the diagonal-block product: their addresses do not depend on the solution
+    const int rr = tid & 127, part = tid >> 7;
+    const int k = k0 - 1 - (((int)blockIdx.x - 1) * HB2_NB + rr);
+    const bool upd = blockIdx.x > 0 && k >= 0 && k0 - k <= bw;
+    const int cb = 16 * part;
+    double lt[16];
+    {
+        const double* col = Bi + (size_t)(upd ? k : 0) * W + (upd ? k0 - k : 0);
+        if (upd && (bw & 1) == 0 && (((size_t)img * n) & 1) == 0 && k0 - k + cb + 15 <= bw && k0 + cb + 15 < n) {
+            // the thread's 16 entries are one 128-byte line: eight 16-byte loads (k(W-1) + k0 is even for even bw)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double2 q = *reinterpret_cast<const double2*>(col + cb + 2 * i);
+                lt[2 * i] = q.x; lt[2 * i + 1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = cb + i;
+                lt[i] = (upd && k0 - k + c <= bw && k0 + c < n) ? col[c] : 0.0;
+            }
+        }
+    }
     if (apply_only) {
         if (blockIdx.x == 0) return;
         if (tid < HB2_NB) xb[tid] = (k0 + tid < n) ? x[(size_t)img * n + k0 + tid] : 0.0;
@@ -484,39 +534,19 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
         if (tid < HB2_NB) xb[tid] = (k0 + tid < n) ? val : 0.0;
     }
     __syncthreads();
-    // earlier equation k: y_k -= sum_c L[k0+c][k] x_{k0+c},  L[k0+c][k] = band[k*W + (k0 + c - k)]
-    const int rr = tid & 127, part = tid >> 7;
-    const int k = k0 - 1 - ((blockIdx.x - 1) * HB2_NB + rr);
     double s = 0.0;
-    if (k >= 0 && k0 - k <= bw) {
-        const double* col = Bi + (size_t)k * W + (k0 - k);
+    if (upd) {
         double a0 = 0.0, a1 = 0.0;
-        const int cb = 16 * part;
-        if ((bw & 1) == 0 && (((size_t)img * n) & 1) == 0 && k0 - k + cb + 15 <= bw && k0 + cb + 15 < n) {
-            // the thread's 16 entries are one 128-byte line: eight 16-byte loads (k(W-1) + k0 is even for even bw)
-            double2 l[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) l[i] = *reinterpret_cast<const double2*>(col + cb + 2 * i);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                a0 = __builtin_fma(l[i].x, xb[cb + 2 * i], a0);
-                a1 = __builtin_fma(l[i].y, xb[cb + 2 * i + 1], a1);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const int c = cb + i;
-                const double l0 = (k0 - k + c <= bw && k0 + c < n) ? col[c] : 0.0;
-                const double l1 = (k0 - k + c + 1 <= bw && k0 + c + 1 < n) ? col[c + 1] : 0.0;
-                a0 = __builtin_fma(l0, xb[c], a0);
-                a1 = __builtin_fma(l1, xb[c + 1], a1);
-            }
+        for (int i = 0; i < 16; i += 2) {
+            a0 = __builtin_fma(lt[i], xb[cb + i], a0);
+            a1 = __builtin_fma(lt[i + 1], xb[cb + i + 1], a1);
         }
         s = a0 + a1;
     }
     red[part * BS_MP + rr] = s;
     __syncthreads();
-    if (tid < HB2_NB && k >= 0 && k0 - k <= bw) {
+    if (tid < HB2_NB && upd) {
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q * BS_MP + tid];

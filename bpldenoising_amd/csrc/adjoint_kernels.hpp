@@ -803,14 +803,17 @@ __global__ __launch_bounds__(256) void patch_sum_kernel(const double* __restrict
 // D = diag(A) (plane 0 of band4).  The diagonally scaled pair is the quality gate: the raw residual is
 // dominated by the rounding of the rows that carry the 1e14 active-set weight (|r_k| ~ eps * 1e14 * |p|),
 // which say nothing about the solve; scaled by 1/sqrt(d_k) = 1e-7 they fall to rounding level.
+// grid (RESN_BLK, O): partials[(img * RESN_BLK + b) * 4 + {0..3}]; adj_resnorm_final_kernel adds them in block order
+// (no atomics: reproducible) into out[img * 4 + {0..3}].
+constexpr int RESN_BLK = 64;
 __global__ __launch_bounds__(256) void adj_resnorm_kernel(const double* __restrict__ r,
                                                           const double* __restrict__ rhs,
                                                           const double* __restrict__ diag, int npx,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ partial) {
     __shared__ double sh[4];
-    const size_t base = (size_t)blockIdx.x * npx;
+    const size_t base = (size_t)blockIdx.y * npx;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int q = threadIdx.x; q < npx; q += 256) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)npx; q += (size_t)RESN_BLK * 256) {
         const double rv = r[base + q], bv = rhs[base + q], di = 1.0 / diag[base + q];
         s0 += rv * rv;
         s1 += bv * bv;
@@ -822,9 +825,17 @@ __global__ __launch_bounds__(256) void adj_resnorm_kernel(const double* __restri
     s2 = block_sum<256>(s2, sh);
     s3 = block_sum<256>(s3, sh);
     if (threadIdx.x == 0) {
-        double* o = out + 4 * (size_t)blockIdx.x;
+        double* o = partial + 4 * ((size_t)blockIdx.y * RESN_BLK + blockIdx.x);
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
     }
+}
+__global__ void adj_resnorm_final_kernel(const double* __restrict__ partial, int O, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;   // (img, component)
+    if (e >= 4 * O) return;
+    const int img = e >> 2, c = e & 3;
+    double s = 0.0;
+    for (int b = 0; b < RESN_BLK; ++b) s += partial[4 * ((size_t)img * RESN_BLK + b) + c];
+    out[e] = s;
 }
 
 }  // namespace bpltv

@@ -617,7 +617,7 @@ int adj_alloc(bpltv_t* h) {
     HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_resn, 4 * (size_t)h->O * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->d_resn, 4 * (size_t)h->O * (1 + RESN_BLK) * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
     h->adj_ready = true;
     return BPLTV_OK;
@@ -849,7 +849,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
         solve(h->d_r, h->d_p);
     }
     hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
-    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_band4, (int)h->npx, h->d_resn);
+    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_band4, (int)h->npx,
+                       h->d_resn + 4 * (size_t)O);
+    hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * O + 63) / 64), dim3(64), 0, h->stream, h->d_resn + 4 * (size_t)O, O, h->d_resn);
     // gradient per pixel, then per parameter
     hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
                        h->d_gpix);
@@ -952,6 +954,10 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
     if (int prc = check_params(h, p)) return prc;
     int rc = upload_alpha(h, alpha, am, an);
     if (rc) return rc;
+    if (h->band_ready && h->adj_hbm && p.reserved[4] != 2) {   // wide images: zero the band while the PDHG solve runs
+        const int prc = h->hb.prefill_async();
+        if (prc) return set_err(h, prc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
+    }
     rc = run_pdhg(h, p);
     if (rc) return rc;
     const double* d_u = h->d_state[h->result_buf][0];
@@ -1208,7 +1214,9 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
         solve(h->d_r, h->d_p);
     }
     residual(h->d_r);
-    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_srdiag, (int)h->npx, h->d_resn);
+    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_srdiag, (int)h->npx,
+                       h->d_resn + 4 * (size_t)O);
+    hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * O + 63) / 64), dim3(64), 0, h->stream, h->d_resn + 4 * (size_t)O, O, h->d_resn);
     hipLaunchKernelGGL(sr_adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg, h->d_srgpix);
     if (am == M && an == N && !(M == 1 && N == 1)) {   // three pixelwise maps: plain sums over the images
         for (int k = 0; k < 3; ++k)
