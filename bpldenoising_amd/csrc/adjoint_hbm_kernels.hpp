@@ -4,10 +4,11 @@
 // band[O][n][W], W = M+1 (column k of the lower band: entry (k+d, k) at d), factored IN PLACE.  The
 // lower band is also a column-major matrix with leading dimension W-1, A(r, c) = band[r + (W-1) c], so
 // dense tile kernels address it directly.  Grid-wide synchronisation is the kernel boundary: per panel
-// of 128 columns three launches (all images in the same launches), built from the dense kernels of the
+// of 128 columns a few launches (all images in the same launches), built from the dense kernels of the
 // block cyclic reduction (adjoint_bcr_kernels.hpp):
-//   hb2_potrf_kernel   diagonal block: Cholesky + inverse in LDS (bcr_potrf_lds_body); L11 to a side buffer,
-//                      L11^-1 and its transpose kept per panel for the substitutions
+//   hb3_chain_kernel   diagonal block: the previous panel's contribution (two 128^3 products on the MFMA, in
+//                      LDS), Cholesky + inverse in LDS (bcr_potrf_lds_body); L11 to a side buffer, L11^-1 and its
+//                      transpose kept per panel for the substitutions
 //   hb2_trsm_kernel    P = A21 L11^-T for the bw rows below (MFMA tiles; side panel buffer P)
 //   hb2_update_kernel  A22 -= P P^T on the lower 64x64 tiles of the trailing bw x bw block (MFMA),
 //                      and L11, P copied into the band
@@ -150,36 +151,13 @@ __global__ __launch_bounds__(256) void hb_tw_vec_kernel(int mode, int bw, int n,
 
 constexpr int HB2_NB = 128;
 
-// grid (O), block BCR_PT, dynamic LDS bcr_potrf_lds(HB2_NB)
-// Linv, LinvT: [O][npanel][128 x 128], kept for the substitutions; L11: [O][128 x 128] (this panel only).
-__global__ __launch_bounds__(BCR_PT) void hb2_potrf_kernel(const double* __restrict__ band, int bw, int n, int k0,
-                                                           int npanel, double* __restrict__ Linv,
-                                                           double* __restrict__ LinvT, double* __restrict__ L11,
-                                                           int* __restrict__ fail) {
-    extern __shared__ double S[];
+// Cholesky factor + inverse of the block in S (bcr_potrf_lds_body) and its three copies: L11 (this panel's
+// Cholesky tile, side buffer), L11^-1 and its transpose (kept per panel for the substitutions).
+__device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img, int k0, int npanel,
+                                                 double* __restrict__ Linv, double* __restrict__ LinvT,
+                                                 double* __restrict__ L11, int* __restrict__ fail) {
     constexpr int MP = HB2_NB, ld = MP + 1;
-    const int W = bw + 1;
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const double* Bi = band + (size_t)img * n * W + (size_t)k0 * W;   // A(k0+r, k0+c) = Bi[r + (W-1) c], r >= c
-    for (int e0 = tid; e0 < MP * MP; e0 += 8 * BCR_PT) {   // batches of 8 independent loads (clamped addresses)
-        double v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            const bool in = (k0 + hi < n) && (hi - lo <= bw);
-            v[i] = Bi[in ? hi + (size_t)(W - 1) * lo : 0];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            double x = (r == c) ? 1.0 : 0.0;   // identity padding past the end of the matrix
-            if (k0 + hi < n) x = (hi - lo <= bw) ? v[i] : 0.0;
-            S[r + ld * c] = x;
-        }
-    }
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
     double* Lg = L11 + (size_t)img * MP * MP;
     const bool bad = bcr_potrf_lds_body(S, MP, Lg, MP);
     if (bad && lane == 0 && fail[img] == 0) fail[img] = k0 + 1;
@@ -192,6 +170,151 @@ __global__ __launch_bounds__(BCR_PT) void hb2_potrf_kernel(const double* __restr
         if ((r >> 4) > (c >> 4)) Lg[e] = S[r + ld * c];          // strictly lower tiles of L
         else if ((r >> 4) < (c >> 4)) Lg[e] = 0.0;               // (diagonal tiles were written by bcr_diag_tile)
     }
+}
+
+// The dependent chain of the banded Cholesky in ONE launch per panel (one workgroup per problem): the diagonal
+// block k receives the contribution of panel k-1 here, in LDS, and is factored at once --
+//     P0 = A(k, k-1) L(k-1,k-1)^-T            (the first 128 rows of panel k-1; its band entries are final once
+//                                              panel k-2's update is done)
+//     D  = A(k, k) - P0 P0^T                  (band entries updated through panel k-2)
+//     L(k,k) = chol(D), L(k,k)^-1
+// so that neither the triangular solve of the whole panel (hb2_trsm_kernel) nor a separate update launch sits
+// between two diagonal blocks: those run behind, on other streams (HbBandSolver::factor_problems).  The band copy of
+// A(k, k) is NOT updated with panel k-1's part (nothing else reads it before L(k,k) overwrites it).
+// k0 = 0: plain diagonal block.  grid (nprob), block BCR_PT, dynamic LDS bcr_potrf_lds(HB2_NB) -- the same 129 x 128
+// array holds A(k, k-1), then P0, then D.
+__global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restrict__ band, int bw, int n, int k0,
+                                                           int npanel, double* __restrict__ Linv,
+                                                           double* __restrict__ LinvT, double* __restrict__ L11,
+                                                           int* __restrict__ fail) {
+    extern __shared__ double S[];
+    constexpr int MP = HB2_NB, ld = MP + 1;
+    const int W = bw + 1;
+    const int img = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const double* Bi = band + (size_t)img * n * W;
+    const double* Bd = Bi + (size_t)k0 * W;                   // A(k0+r, k0+c) = Bd[r + (W-1) c], r >= c
+    if (k0 == 0) {
+        for (int e0 = tid; e0 < MP * MP; e0 += 8 * BCR_PT) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
+                const int lo = r < c ? r : c, hi = r < c ? c : r;
+                const bool in = (hi < n) && (hi - lo <= bw);
+                v[i] = Bd[in ? hi + (size_t)(W - 1) * lo : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
+                const int lo = r < c ? r : c, hi = r < c ? c : r;
+                double x = (r == c) ? 1.0 : 0.0;
+                if (hi < n) x = (hi - lo <= bw) ? v[i] : 0.0;
+                S[r + ld * c] = x;
+            }
+        }
+        __syncthreads();
+        hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, L11, fail);
+        return;
+    }
+    // Every global operand is requested here, before anything waits: A(k, k-1) (32 entries per thread), this wave's
+    // tiles of D and its rows of Linv(k-1) land together after one memory latency.
+    // A(k0 + r, k0 - 128 + c), e = r + 128 c
+    double av[MP * MP / BCR_PT];
+    {
+        const double* Bp = Bi + (size_t)(k0 - MP) * W;        // column k0-128+c at Bp + c W, row k0+r at offset 128 + r - c
+#pragma unroll
+        for (int i = 0; i < MP * MP / BCR_PT; ++i) {
+            const int e = tid + i * BCR_PT, r = e % MP, c = e / MP, off = MP + r - c;
+            const bool in = (k0 + r < n) && (off <= bw);
+            av[i] = in ? Bp[(size_t)c * W + off] : 0.0;
+        }
+    }
+    // P0 column tile jw of this wave (waves w and w+4 share a SIMD: jw and 7-jw balance its MFMA work); its B
+    // operands Linv(16 jw + lr, k), k < 16 (jw + 1), in MFMA order: 16 consecutive doubles per k
+    constexpr int NT = MP / 16;
+    const int jw = wave < 4 ? wave : 11 - wave;
+    double lb[4 * NT];
+    {
+        const double* Lp = Linv + ((size_t)img * npanel + (k0 / MP - 1)) * MP * MP;
+#pragma unroll
+        for (int k4 = 0; k4 < 4 * NT; ++k4) {
+            const int kq = 4 * k4 + lk;
+            lb[k4] = (k4 < 4 * (jw + 1)) ? Lp[(16 * jw + lr) + (size_t)MP * kq] : 0.0;
+        }
+    }
+    // lower 16x16 tiles of D, dealt round-robin over the 8 waves: tile t -> (I, J), I >= J
+    constexpr int NTRI = NT * (NT + 1) / 2, TPW = (NTRI + BCR_PT / 64 - 1) / (BCR_PT / 64);
+    int tI[TPW], tJ[TPW];
+    bcr_d4 dacc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        int t = wave + (BCR_PT / 64) * q, a = 0;
+        const bool have = t < NTRI;
+        if (!have) t = 0;
+        while (t > a) { t -= a + 1; ++a; }
+        tI[q] = have ? a : -1; tJ[q] = t;
+        // D(R, C), R = 16 I + lk + 4 g, C = 16 J + lr
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int R = 16 * a + lk + 4 * g, C = 16 * t + lr;
+            const int lo = R < C ? R : C, hi = R < C ? C : R;
+            double x = (R == C) ? 1.0 : 0.0;   // identity padding past the end of the matrix
+            if (k0 + hi < n) x = (hi - lo <= bw) ? Bd[hi + (size_t)(W - 1) * lo] : 0.0;
+            dacc[q][g] = have ? x : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MP * MP / BCR_PT; ++i) {
+        const int e = tid + i * BCR_PT;
+        S[(e % MP) + ld * (e / MP)] = av[i];
+    }
+    __syncthreads();
+    // P0 tile (i, jw) = sum over k-blocks kb <= jw of A(i, kb) Linv(jw, kb)^T for the 8 row tiles i
+    {
+        bcr_d4 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k4 = 0; k4 < 4 * NT; ++k4) {
+            if (k4 < 4 * (jw + 1)) {   // wave-uniform
+                const int kq = 4 * k4 + lk;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i] = bcr_mfma(S[(16 * i + lr) + ld * kq], lb[k4], acc[i]);
+            }
+        }
+        __syncthreads();   // every wave is done with A(k, k-1)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * jw + lr)] = acc[i][g];
+    }
+    __syncthreads();
+    // D tile (I, J) -= sum_k P0(16 I + r, k) P0(16 J + c, k)
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        if (tI[q] < 0) continue;
+        const int ra = 16 * tI[q] + lr, rb = 16 * tJ[q] + lr;
+        bcr_d4 acc = dacc[q];
+#pragma unroll 8
+        for (int k4 = 0; k4 < MP / 4; ++k4) {
+            const int kq = 4 * k4 + lk;
+            acc = bcr_mfma(-S[ra + ld * kq], S[rb + ld * kq], acc);
+        }
+        dacc[q] = acc;
+    }
+    __syncthreads();       // every wave is done with P0
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        if (tI[q] < 0) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int R = 16 * tI[q] + lk + 4 * g, C = 16 * tJ[q] + lr;
+            S[R + ld * C] = dacc[q][g];
+            if (tI[q] != tJ[q]) S[C + ld * R] = dacc[q][g];   // the upper triangle mirrors the lower
+        }
+    }
+    __syncthreads();
+    hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, L11, fail);
 }
 
 // 64 x 32 chunk of the band as an MFMA operand: rows R0 + (tid & 63), columns K0 + (tid >> 6) + 4 i.
@@ -276,14 +399,15 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
 
 // Trailing update A(R, C) -= sum_k P(R, k) P(C, k) on the lower 64x64 tiles (ta >= tb) of the bw x bw block
 // behind the panel, in three launches per panel (nt = ceil(bw/64) tile rows):
-//   part 0  the three tiles of the next panel's diagonal block -- all the next hb2_potrf_kernel needs;
+//   part 0  the three tiles of the next panel's diagonal block;
 //   part 1  what the next panel's hb2_trsm_kernel and first update read or overwrite: the rest of the first
 //           128-column block (tiles (ta, 0), (ta, 1), ta >= 2) and the tiles (2,2), (3,2), (3,3) of the diagonal
 //           block after next; its workgroups also copy the finished panel (L11, and P = L21) into the band, which
 //           only the substitutions read -- they are done before the side buffers are reused two panels later;
-//   part 2  everything else (tb >= 2), which only has to precede the same tiles' update by the next panel.
-// Parts 1 and 2 run on a second stream; the main stream waits for part 1 only, so part 2 of panel k overlaps
-// with the diagonal block, triangular solve and first update of panel k + 1.
+//   part 2  everything else (tb >= 2), which only has to precede the same tiles' update by the next panel;
+//   part 5  no tile: the copies only.
+// Which launches a panel gets and on which streams: HbBandSolver::factor_problems (Cholesky; part 0 only for the last
+// panel, the others' diagonal blocks are updated inside hb3_chain_kernel) and HbLuSolver::factor (all parts in order).
 // grid (hb2_update_tiles(nt, part) * nprob), workgroup id = tile * nprob + problem: ids of equal residue mod 8
 // share an XCD (observed round-robin placement; speed only), so with nprob a multiple of 8 every L2 serves the
 // 1 MB panels P of nprob / 8 problems instead of all of them; block BG_T.
@@ -298,8 +422,9 @@ __host__ __device__ inline int hb2_update_tiles(int nt, int part) {
     return rest > 0 ? rest : 0;
 }
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int bw, int n, int k0,
-                                                          const double* __restrict__ L11, const double* __restrict__ P,
-                                                          int bwp, int part, int nprob, const double* __restrict__ PB = nullptr) {
+                                                          const double* __restrict__ P, int bwp, int part, int nprob,
+                                                          const double* __restrict__ PB, const double* __restrict__ cpL11,
+                                                          const double* __restrict__ cpP, int cpk0) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
     const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
@@ -324,21 +449,24 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
             else if (j == 1 && nt >= 4) { ta = 3; tb = 2; }
             else if (j == 2 && nt >= 4) { ta = 3; tb = 3; }
         }
-    } else {
+    } else if (part == 2) {
         int t = bx + ((nt >= 4) ? 3 : ((nt == 3) ? 1 : 0)), a = 0;
         while (t > a) { t -= a + 1; ++a; }
         ta = a + 2; tb = t + 2;
     }
     const int base = k0 + HB2_NB;
-    // Copies of the finished panel into the band (only the substitutions read them), off the critical path of the
-    // next panel's Cholesky: item 0 = L11, item 1 + t = rows [64 t, 64 t + 64) of L21, dealt round-robin over the
-    // workgroups of part 1.  Explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory
-    // latency per iteration.
-    if (part == 1) {
+    // Copies of a finished panel (the one that starts at column cpk0: this panel, or an earlier one whose band
+    // entries were still being read) into the band -- only the substitutions read them -- off the critical path of
+    // the next panel's Cholesky: item 0 = L11, item 1 + t = rows [64 t, 64 t + 64) of L21, dealt round-robin over
+    // the workgroups of the launch.  Explicit batches of 16 loads, then the stores: a rolled copy loop pays one
+    // memory latency per iteration.
+    if (cpP) {
+        const int cbase = cpk0 + HB2_NB;
+        const double* Pc = cpP + (size_t)img * bwp * HB2_NB;
         for (int item = bx; item < 1 + nt; item += gx) {
             if (item == 0) {
-                if (!L11) continue;   // LU path: the diagonal block of L is the identity
-                const double* Lg = L11 + (size_t)img * HB2_NB * HB2_NB;
+                if (!cpL11) continue;   // LU path: the diagonal block of L is the identity
+                const double* Lg = cpL11 + (size_t)img * HB2_NB * HB2_NB;
                 for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
                     double v[16];
 #pragma unroll
@@ -346,23 +474,23 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int e = e0 + i * BG_T, r = e % HB2_NB, c = e / HB2_NB;
-                        if (r >= c && k0 + r < n && r - c <= bw) Bi[(size_t)(k0 + c) * W + (r - c)] = v[i];
+                        if (r >= c && cpk0 + r < n && r - c <= bw) Bi[(size_t)(cpk0 + c) * W + (r - c)] = v[i];
                     }
                 }
             } else {
                 const int tc = item - 1;
-                if (base + 64 * tc >= n) continue;
+                if (cbase + 64 * tc >= n) continue;
                 for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
                     double v[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int e = e0 + i * BG_T;
-                        v[i] = Pi[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
+                        v[i] = Pc[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
-                        const int R = base + rr, K = k0 + c;
+                        const int R = cbase + rr, K = cpk0 + c;
                         if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
                     }
                 }
@@ -414,7 +542,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 // Substitutions with L in the band array, one launch per 128-column block (a single workgroup streaming
 // the 8.6 GB factor of a 1024^2 image would be limited to one CU's bandwidth; the kernel boundary is the
 // grid-wide synchronisation).  Every 1024-thread workgroup recomputes the block's solution with the
-// inverted diagonal block of hb2_potrf_kernel (the whole 128 KB block requested at once, as in the
+// inverted diagonal block of hb3_chain_kernel (the whole 128 KB block requested at once, as in the
 // substitutions of the block cyclic reduction); workgroup 0 stores it, workgroup 1+j applies it to its
 // 128 rows of the band (thread (row, part): 16 consecutive columns each, partial sums meet in LDS).
 // Forward (L y = b):   in/out `x` = running right-hand side, solution rows -> `y`.

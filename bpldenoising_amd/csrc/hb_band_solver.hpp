@@ -48,8 +48,10 @@ struct HbBandSolver {
     double* bufm = nullptr;      // middle problems
     double* vec = nullptr;       // twisted solve: vs | ys | xs ([O*2][np] each) | vm | ym | xm ([O][nm] each)
     int* fail = nullptr;         // [O*sides + O]
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // C -> T, T -> U2, prefill
+    hipEvent_t ev1[2] = {nullptr, nullptr};           // U1 of even / odd panels
+    hipEvent_t ev2 = nullptr;                         // U2
     bool prefilled = false;      // the band has been zero-filled ahead of factor() (prefill_async)
     bool single_stream = false;  // profiling aid (BPLTV_HB_SINGLE_STREAM=1): rocprofv3 --pmc cannot follow two streams
     std::string err;
@@ -60,7 +62,7 @@ struct HbBandSolver {
     };
     static size_t bufs_doubles(int nprob, int ncol, int bw) {
         const size_t npanel = (size_t)(ncol + HB2_NB - 1) / HB2_NB, bwp = (size_t)(bw + 63) / 64 * 64;
-        return (size_t)nprob * ((2 * npanel + 2) * HB2_NB * HB2_NB + 2 * bwp * HB2_NB);
+        return (size_t)nprob * ((2 * npanel + 3) * HB2_NB * HB2_NB + 3 * bwp * HB2_NB);
     }
     static Bufs carve(double* base, int nprob, int ncol) {
         Bufs b;
@@ -68,8 +70,8 @@ struct HbBandSolver {
         const size_t blk = (size_t)nprob * HB2_NB * HB2_NB;
         b.Linv = base;
         b.LinvT = base + blk * b.npanel;
-        b.L11 = b.LinvT + blk * b.npanel;   // two buffers (panel parity)
-        b.P = b.L11 + 2 * blk;              // two buffers of nprob * bwp * 128 doubles (panel parity)
+        b.L11 = b.LinvT + blk * b.npanel;   // three buffers (panel index mod 3)
+        b.P = b.L11 + 3 * blk;              // three buffers of nprob * bwp * 128 doubles
         return b;
     }
 
@@ -122,14 +124,17 @@ struct HbBandSolver {
             HBCHK(hipMalloc((void**)&bufm, bufs_doubles(O, nm, bw) * sizeof(double)));
             HBCHK(hipMalloc((void**)&vec, (size_t)O * (6 * (size_t)np + 3 * (size_t)nm) * sizeof(double)));
         }
-        HBCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hb2_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HBCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hb3_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bcr_potrf_lds(HB2_NB)));
         {   // the bulk of the trailing update yields to the dependent chain on the main stream
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HBCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least));
+            HBCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, greatest));
+            HBCHK(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, least));
         }
         for (auto& e : ev) HBCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : ev1) HBCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HBCHK(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
         return 0;
     }
 
@@ -138,44 +143,92 @@ struct HbBandSolver {
             if (p) (void)hipFree(p);
         band = mid = buf = bufm = vec = nullptr; fail = nullptr;
         for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& e : ev1) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (ev2) (void)hipEventDestroy(ev2);
+        ev2 = nullptr;
         if (stream2) (void)hipStreamDestroy(stream2);
-        stream2 = nullptr;
+        if (stream3) (void)hipStreamDestroy(stream3);
+        stream2 = stream3 = nullptr;
     }
 
-    // Right-looking blocked Cholesky of `nprob` band problems of `nrow` rows, eliminating columns [0, nelim).
-    // Main stream, per panel of 128 columns: potrf -> [part 1 of the previous panel's update done] -> trsm ->
-    // update part 0 (the next diagonal block).  Second stream: update part 1 (what the next trsm needs, and the
-    // copies of the finished panel), then part 2 (the bulk), which overlaps with the next panel's chain.
-    // Side buffers L11 and P alternate by panel parity: panel k+1 writes them while part 2 of panel k still reads.
+    // Right-looking blocked Cholesky of `nprob` band problems of `nrow` rows, eliminating columns [0, nelim), as a
+    // three-stream pipeline over the panels of 128 columns (k = panel index):
+    //   main stream   C(k)  = hb3_chain_kernel: diagonal block k minus panel k-1's contribution, Cholesky, inverse.
+    //                 The dependent chain of the whole factorisation is C(0), C(1), ... back to back.
+    //   stream2       T(k)  = hb2_trsm_kernel (after C(k)): the panel P = L21;
+    //                 U1(k) = update part 1 (block column k+1 below its diagonal block and diagonal block k+2), plus
+    //                         the copies of panel k-1 into the band (C(k) has read the entries they overwrite)
+    //   stream3       U2(k) = update part 2 (the bulk, block columns >= k+2), after T(k), lowest priority.
+    // C(k) needs U1(k-2) (and through it everything older); U1(k) needs U2(k-1) (same tiles); the rest is stream order.
+    // So the triangular solve and both updates of panel k overlap with C(k+1).  Diagonal block k+1 is not updated in
+    // the band (C(k+1) does it in LDS) except behind the last panel, where part 0 runs.  Side buffers L11 and P
+    // rotate over three slots: slot k is read until U1(k+1)'s copies, rewritten by C(k+3) / T(k+3).
     int factor_problems(double* B, int nprob, int nrow, int nelim, const Bufs& hb, int* d_fail) {
         const int nt = (bw + 63) / 64, bwp = nt * 64;
         const int g0 = hb2_update_tiles(nt, 0), g1 = hb2_update_tiles(nt, 1), g2 = hb2_update_tiles(nt, 2);
-        bool part1_pending = false;
-        hipStream_t s2 = single_stream ? stream : stream2;
-        for (int k0 = 0; k0 < nelim; k0 += HB2_NB) {
-            const int par = (k0 / HB2_NB) & 1;
-            double* L11p = hb.L11 + (size_t)par * nprob * HB2_NB * HB2_NB;
-            double* Pp = hb.P + (size_t)par * nprob * bwp * HB2_NB;
-            hipLaunchKernelGGL(hb2_potrf_kernel, dim3(nprob), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, B, bw, nrow, k0,
+        hipStream_t sA = single_stream ? stream : stream2, sB = single_stream ? stream : stream3;
+        const size_t blk = (size_t)nprob * HB2_NB * HB2_NB, pblk = (size_t)nprob * bwp * HB2_NB;
+        const double* nul = nullptr;
+        int k = 0, klast = -1;
+        for (int k0 = 0; k0 < nelim; k0 += HB2_NB, ++k) {
+            double* L11p = hb.L11 + (size_t)(k % 3) * blk;
+            double* Pp = hb.P + (size_t)(k % 3) * pblk;
+            const double* L11q = k > 0 ? hb.L11 + (size_t)((k - 1) % 3) * blk : nul;
+            const double* Pq = k > 0 ? hb.P + (size_t)((k - 1) % 3) * pblk : nul;
+            const bool last = k0 + HB2_NB >= nelim;
+            if (k >= 2 && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev1[k & 1], 0));   // U1(k-2)
+            hipLaunchKernelGGL(hb3_chain_kernel, dim3(nprob), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, B, bw, nrow, k0,
                                hb.npanel, hb.Linv, hb.LinvT, L11p, d_fail);
-            if (part1_pending && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
-            part1_pending = false;
-            if (k0 + HB2_NB < nrow)
-                hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, hb.npanel, hb.Linv, Pp,
-                                   bwp, nprob, 0);
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, stream, B, bw, nrow, k0, L11p, Pp, bwp, 0, nprob, (const double*)nullptr);
+            klast = k;
+            if (k0 + HB2_NB >= nrow) {   // nothing below: only the copies are left (this panel's follow the loop)
+                if (k >= 1) {
+                    if (!single_stream) {
+                        HBCHK(hipEventRecord(ev[0], stream));
+                        HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
+                    }
+                    hipLaunchKernelGGL(hb2_update_kernel, dim3((1 + nt) * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, nul, bwp, 5, nprob,
+                                       nul, L11q, Pq, k0 - HB2_NB);
+                }
+                break;
+            }
             if (!single_stream) {
                 HBCHK(hipEventRecord(ev[0], stream));
-                HBCHK(hipStreamWaitEvent(s2, ev[0], 0));
+                HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
             }
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 1, nprob, (const double*)nullptr);
-            if (!single_stream) HBCHK(hipEventRecord(ev[1], s2));
-            part1_pending = true;
-            if (g2 > 0) hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, s2, B, bw, nrow, k0, L11p, Pp, bwp, 2, nprob, (const double*)nullptr);
+            hipLaunchKernelGGL(hb2_trsm_kernel, dim3(2 * nt * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, hb.npanel, hb.Linv, Pp,
+                               bwp, nprob, 0);
+            if (!single_stream && g2 > 0) {
+                HBCHK(hipEventRecord(ev[1], sA));
+                HBCHK(hipStreamWaitEvent(sB, ev[1], 0));
+            }
+            if (last)   // no chain kernel follows: the next diagonal block is updated in the band
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 0,
+                                   nprob, nul, nul, nul, 0);
+            if (k >= 1 && !single_stream && g2 > 0) HBCHK(hipStreamWaitEvent(sA, ev2, 0));     // U2(k-1)
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 1, nprob,
+                               nul, L11q, Pq, k0 - HB2_NB);
+            if (!single_stream) HBCHK(hipEventRecord(ev1[k & 1], sA));
+            if (g2 > 0) {
+                hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, sB, B, bw, nrow, k0, (const double*)Pp, bwp, 2,
+                                   nprob, nul, nul, nul, 0);
+                if (!single_stream) HBCHK(hipEventRecord(ev2, sB));
+            }
         }
-        if (!single_stream) {   // join: everything on the second stream is complete before the caller continues
-            HBCHK(hipEventRecord(ev[1], s2));
-            HBCHK(hipStreamWaitEvent(stream, ev[1], 0));
+        if (klast >= 0) {   // the last panel's copies (its L11; its P when rows lie below it)
+            const int k0 = klast * HB2_NB;
+            if (!single_stream) {
+                HBCHK(hipEventRecord(ev[0], stream));
+                HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
+            }
+            hipLaunchKernelGGL(hb2_update_kernel, dim3((1 + nt) * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, nul, bwp, 5, nprob, nul,
+                               (const double*)(hb.L11 + (size_t)(klast % 3) * blk),
+                               (const double*)(hb.P + (size_t)(klast % 3) * pblk), k0);
+        }
+        if (!single_stream) {   // join: both side streams are complete before the caller continues
+            HBCHK(hipEventRecord(ev1[0], sA));
+            HBCHK(hipStreamWaitEvent(stream, ev1[0], 0));
+            HBCHK(hipEventRecord(ev2, sB));
+            HBCHK(hipStreamWaitEvent(stream, ev2, 0));
         }
         HBCHK(hipGetLastError());
         return 0;

@@ -53,7 +53,13 @@ def aggregate(d):
         rows = []
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+                nm = short(r["Kernel_Name"])
+                if nm.startswith("hb2_update"):   # the parts of the trailing update differ by their grid only
+                    try:
+                        nm += "[%d wg]" % (int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+                    except (KeyError, ValueError):
+                        pass
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm))
         rows.sort()
         agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
         prev_end = None
