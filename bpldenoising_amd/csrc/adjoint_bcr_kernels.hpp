@@ -33,6 +33,13 @@ namespace bpltv {
 
 typedef double bcr_d4 __attribute__((ext_vector_type(4)));
 
+#ifdef BCR_PROBE_ON   // tools/potrf_probe.hip only: time stamps (s_memrealtime, 100 MHz) of workgroup 0's phases
+__device__ long long bcr_probe_buf[64];
+#define BCR_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) bcr_probe_buf[i] = (long long)wall_clock64(); } while (0)
+#else
+#define BCR_PROBE(i) do { } while (0)
+#endif
+
 #ifdef BCR_DBG   // timing experiments of tools/bcr_unit.hip only (results are wrong when set)
 __device__ int bcr_dbg = 0;   // 1 skip operand global loads, 2 skip MFMAs, 4 skip LDS staging, 8 skip the output phase
 #define BCR_DBG_ON(bit) (bcr_dbg & (bit))
@@ -88,42 +95,12 @@ __global__ __launch_bounds__(256) void bcr_init_kernel(const double* __restrict_
     }
 }
 
-// Cholesky factor of the 16x16 tile T (LDS, leading dimension ld) and its inverse, by one wave:
-// lane r holds row r, pivots and multipliers travel by readlane.  On exit the tile holds W = L^-1
-// (lower triangular, explicit zeros above).  Returns true on a non-positive pivot.
-__device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, int lane, double* __restrict__ Lg = nullptr,
-                                              int ldg = 0) {
+// Inverse of the lower triangular 16x16 tile T (LDS, leading dimension ld) in place, by one wave: lane c computes
+// column c of W = L^-1 by forward substitution; L(r, k) is read from the tile as an LDS broadcast, 1 / L(r, r) from
+// di[r].  On exit the tile holds W (lower triangular, explicit zeros above).
+__device__ __forceinline__ void bcr_tile_inverse(double* __restrict__ T, int ld, int lane, const double* __restrict__ di) {
     const int lr = lane & 15;
-    double m[16], di[16], x[16];
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) m[c] = T[lr + ld * c];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const double piv = readlane_f64(m[c], c);
-        if (!(piv > 0.0)) bad = true;
-        double d;
-        sqrt_rsqrt(piv, d, di[c]);
-        m[c] = (lr == c) ? d : m[c] * di[c];
-#pragma unroll
-        for (int q = c + 1; q < 16; ++q) {
-            const double lq = readlane_f64(m[c], q);
-            m[q] = __builtin_fma(-m[c], lq, m[q]);
-        }
-    }
-    // lane c computes column c of W = L^-1 by forward substitution; L(r, k) is read back from the
-    // tile as an LDS broadcast (120 readlane pairs would not fit the SGPR file)
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) T[lane + ld * c] = m[c];
-        if (Lg) {   // the Cholesky tile itself (lower), for callers that keep L (banded factorisation)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Lg[lane + (size_t)ldg * c] = (c <= lane) ? m[c] : 0.0;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double x[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         double acc = (lr == r) ? 1.0 : 0.0;
@@ -137,24 +114,108 @@ __device__ __forceinline__ bool bcr_diag_tile(double* __restrict__ T, int ld, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[r + ld * lane] = x[r];
     }
+}
+
+// Tile (p, q), q < p, of W = L^-1:  W_pq = -W_pp sum_{k=q}^{p-1} L_pk W_kq, by one wave on the MFMA.
+// W_kq (k >= q) is kept in the upper tile (q, k): element (r', c') at S[(16q+r') + ld(16k+c')].
+__device__ __forceinline__ void bcr_winv_tile(double* __restrict__ S, int ld, int p, int q, int lr, int lk) {
+    bcr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = q; k < p; ++k) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = S[(16 * p + lr) + ld * (16 * k + 4 * kk + lk)];      // L_pk(r, k')
+            const double b = S[(16 * q + 4 * kk + lk) + ld * (16 * k + lr)];      // W_kq(k', col)
+            acc = bcr_mfma(a, b, acc);
+        }
+    }
+    bcr_d4 out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = S[(16 * p + lr) + ld * (16 * p + 4 * kk + lk)];          // W_pp(r, k')
+        out = bcr_mfma(-a, acc[kk], out);  // the accumulator tile is the B operand of k-step kk
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) S[(16 * q + lk + 4 * g) + ld * (16 * p + lr)] = out[g];
+}
+
+// Block column p (16 columns, rows 16p .. MP-1, already updated with the columns to its left) of the matrix in S,
+// factored by one wave in registers: lane l holds row 16p + l (and row 16p + 64 + l when TWO: more than 64 rows).
+// Per pivot: rsqrt chain on the broadcast pivot, scaling, rank-1 update of the columns to the right with the pivot
+// column's entries L(16p + q, c) broadcast by readlane.  Writes L back (zeros above the diagonal of the diagonal
+// tile) and 1 / L(r, r) to dinv.
+template <bool TWO>
+__device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld, int MP, int p, int lane,
+                                                 double* __restrict__ dinv) {
+    const int r0 = 16 * p + lane, r1 = r0 + 64;
+    const bool v0 = r0 < MP, v1 = TWO && r1 < MP;
+    double m0[16], m1[16], dv[16], dd[16];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        m0[c] = v0 ? S[r0 + ld * (16 * p + c)] : 0.0;
+        if (TWO) m1[c] = v1 ? S[r1 + ld * (16 * p + c)] : 0.0;
+    }
+    // Left-looking inside the block column, written in the order the dependent chain wants: column q receives its
+    // last term (from column q-1), its pivot goes into the rsqrt chain, and while that runs column q+1 is brought up
+    // to date with the columns 0..q-1.  Every broadcast entry L(16p + q, c) = readlane(column c, q) is used at once.
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (q > 0) {
+            const double l = readlane_f64(m0[q - 1], q);
+            m0[q] = __builtin_fma(-m0[q - 1], l, m0[q]);
+            if (TWO) m1[q] = __builtin_fma(-m1[q - 1], l, m1[q]);
+        }
+        const double piv = readlane_f64(m0[q], q);
+        if (!(piv > 0.0)) bad = true;
+        sqrt_rsqrt(piv, dd[q], dv[q]);
+        if (q + 1 < 16) {
+#pragma unroll
+            for (int c = 0; c < q; ++c) {
+                const double l = readlane_f64(m0[c], q + 1);
+                m0[q + 1] = __builtin_fma(-m0[c], l, m0[q + 1]);
+                if (TWO) m1[q + 1] = __builtin_fma(-m1[c], l, m1[q + 1]);
+            }
+        }
+        m0[q] *= dv[q];   // the scaled column (its diagonal entry, the sqrt, is merged in at the write-back)
+        if (TWO) m1[q] *= dv[q];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (v0) S[r0 + ld * (16 * p + c)] = (lane < 16 && c >= lane) ? ((c == lane) ? dd[c] : 0.0) : m0[c];
+        if (TWO && v1) S[r1 + ld * (16 * p + c)] = m1[c];
+    }
+    if (lane < 16) {
+        double mine = dv[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) mine = (lane == c) ? dv[c] : mine;
+        dinv[16 * p + lane] = mine;
+    }
     return bad;
 }
 
-// Cholesky factor and its inverse of the symmetric MP x MP matrix held in LDS (S[r + (MP+1) c], both
-// triangles), by the BCR_PT threads of the workgroup.  On exit the lower tiles of S hold L (strictly
-// below the diagonal tiles) and the diagonal + upper tiles hold W = L^-1: W(r, c), r >= c, at
-// S[(16*(c>>4) + (r&15)) + ld*(16*(r>>4) + (c&15))].  Lg (nullable, leading dimension ldg): receives the
-// diagonal tiles of L.  Returns true (in wave 0) on a non-positive pivot.
+// Cholesky factor and its inverse of the symmetric MP x MP matrix held in LDS (S[r + (MP+1) c], lower triangle read),
+// by the BCR_PT threads of the workgroup; S is followed by MP doubles of scratch (bcr_potrf_lds).  On exit the lower
+// tiles of S hold L (strictly below the diagonal tiles) and the diagonal + upper tiles hold W = L^-1: W(r, c), r >= c,
+// at S[(16*(c>>4) + (r&15)) + ld*(16*(r>>4) + (c&15))].  Returns true (in wave 0) on a non-positive pivot.
+//
+// The dependent chain is MP pivots long; everything else is kept off it.  Per block column p (16 columns):
+//   (1) all waves: left-looking update, tile (i, p) -= sum_{q<p} L_iq L_pq^T on the MFMA
+//   (2) wave 0: the whole block column -- up to 128 rows, lane l holds rows 16p + l and 16p + 64 + l -- is factored
+//       in registers: per pivot one rsqrt chain, then rank-1 updates with the pivot column's entries broadcast by
+//       readlane.  The rows below the diagonal tile come out as L directly (no product with an inverted diagonal tile).
+//       Meanwhile wave 1 inverts diagonal tile p-1 and waves 2.. compute row p-2 of W (bcr_winv_tile): the inverse
+//       trails the factorisation by two block columns and costs the chain nothing but a short tail.
 constexpr int BCR_PT = 512;
-__device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int MP, double* __restrict__ Lg = nullptr,
-                                                   int ldg = 0) {
+__device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int MP) {
     const int ld = MP + 1, P = MP >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    constexpr int NW = BCR_PT / 64;
+    double* dinv = S + (size_t)ld * MP;   // 1 / L(r, r)
     bool bad = false;
     for (int p = 0; p < P; ++p) {
-        // (1) left-looking update of block column p: tile (i, p) -= sum_{q<p} L_iq L_pq^T
+        // (1) left-looking update of block column p
         if (p > 0) {
-            for (int i = p + wave; i < P; i += BCR_PT / 64) {
+            for (int i = p + wave; i < P; i += NW) {
                 bcr_d4 acc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)];
@@ -171,52 +232,31 @@ __device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int M
             }
             __syncthreads();
         }
-        // (2) diagonal tile: Cholesky and inverse in wave-0 registers (lane r holds row r)
-        if (wave == 0)
-            bad |= bcr_diag_tile(S + (16 * p) + ld * (16 * p), ld, lane, Lg ? Lg + 16 * p + (size_t)ldg * (16 * p) : nullptr, ldg);
-        __syncthreads();
-        // (3) rows below: L_ip = A_ip W_pp^T      (4) inverse row panel: W_pq = -W_pp sum_k L_pk W_kq
-        //     W_kq (k >= q) is kept in the upper tile (q, k): element (r', c') at S[(16q+r') + ld(16k+c')]
-        for (int task = wave; task < P - 1; task += BCR_PT / 64) {
-            if (task < P - p - 1) {
-                const int i = p + 1 + task;
-                bcr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double a = S[(16 * i + lr) + ld * (16 * p + 4 * kk + lk)];
-                    const double b = S[(16 * p + lr) + ld * (16 * p + 4 * kk + lk)];  // W_pp(col, k)
-                    acc = bcr_mfma(a, b, acc);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)] = acc[g];
-            } else {
-                const int q = task - (P - p - 1);
-                bcr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int k = q; k < p; ++k) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double a = S[(16 * p + lr) + ld * (16 * k + 4 * kk + lk)];      // L_pk(r, k')
-                        const double b = S[(16 * q + 4 * kk + lk) + ld * (16 * k + lr)];      // W_kq(k', col)
-                        acc = bcr_mfma(a, b, acc);
-                    }
-                }
-                bcr_d4 out = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double a = S[(16 * p + lr) + ld * (16 * p + 4 * kk + lk)];          // W_pp(r, k')
-                    out = bcr_mfma(-a, acc[kk], out);  // the accumulator tile is the B operand of k-step kk
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) S[(16 * q + lk + 4 * g) + ld * (16 * p + lr)] = out[g];
-            }
+        BCR_PROBE(8 + 2 * p);
+        if (wave == 0) {
+            // (2) block column p in registers
+            if (MP - 16 * p > 64) bad |= bcr_panel_factor<true>(S, ld, MP, p, lane, dinv);
+            else bad |= bcr_panel_factor<false>(S, ld, MP, p, lane, dinv);
+        } else if (wave == 1) {
+            if (p >= 1) bcr_tile_inverse(S + 16 * (p - 1) + ld * (16 * (p - 1)), ld, lane, dinv + 16 * (p - 1));
+        } else if (p >= 2) {
+            for (int q = wave - 2; q < p - 2; q += NW - 2) bcr_winv_tile(S, ld, p - 2, q, lr, lk);
         }
         __syncthreads();
+        BCR_PROBE(9 + 2 * p);
     }
+    // tail: the last diagonal tile and the last two rows of W
+    if (wave == 0) bcr_tile_inverse(S + 16 * (P - 1) + ld * (16 * (P - 1)), ld, lane, dinv + 16 * (P - 1));
+    else if (wave >= 2 && P >= 2)
+        for (int q = wave - 2; q < P - 2; q += NW - 2) bcr_winv_tile(S, ld, P - 2, q, lr, lk);
+    __syncthreads();
+    for (int q = wave; q < P - 1; q += NW) bcr_winv_tile(S, ld, P - 1, q, lr, lk);
+    __syncthreads();
     return bad;
 }
 
 // Cholesky factor of D_j and its inverse, in LDS.  grid (nelim, O) (or (1, O) with s = 0 for the
-// last block 0), block BCR_PT; dynamic LDS (MP+1)*MP doubles.  On exit D_j holds L^-1 (lower
+// last block 0), block BCR_PT; dynamic LDS bcr_potrf_lds(MP).  On exit D_j holds L^-1 (lower
 // triangular, zeros above) and DT_j its transpose.
 __global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ D, double* __restrict__ DT, int N,
                                                            int MP, int s, int* __restrict__ fail) {
@@ -1006,7 +1046,7 @@ struct BcrArrays {
                          base + 7 * a, base + 7 * a + (size_t)O * N * M, base + 7 * a + 2 * (size_t)O * N * M};
     }
 };
-inline size_t bcr_potrf_lds(int MP) { return (size_t)(MP + 1) * MP * sizeof(double); }
+inline size_t bcr_potrf_lds(int MP) { return ((size_t)(MP + 1) * MP + MP) * sizeof(double); }   // matrix + 1/diag(L)
 inline size_t bcr0_schur_lds(int MP) { return ((size_t)(MP + 1) * MP + 15 * (size_t)(MP + 1)) * sizeof(double); }
 
 // Dense levels l >= l0 of the factorisation of the block tridiagonal matrices held in

@@ -7,11 +7,11 @@
 // of 128 columns a few launches (all images in the same launches), built from the dense kernels of the
 // block cyclic reduction (adjoint_bcr_kernels.hpp):
 //   hb3_chain_kernel   diagonal block: the previous panel's contribution (two 128^3 products on the MFMA, in
-//                      LDS), Cholesky + inverse in LDS (bcr_potrf_lds_body); L11 to a side buffer, L11^-1 and its
-//                      transpose kept per panel for the substitutions
+//                      LDS), Cholesky + inverse in LDS (bcr_potrf_lds_body); L11^-1 and its transpose kept per
+//                      panel (the panel solve and the substitutions use them; L11 itself is not stored)
 //   hb2_trsm_kernel    P = A21 L11^-T for the bw rows below (MFMA tiles; side panel buffer P)
 //   hb2_update_kernel  A22 -= P P^T on the lower 64x64 tiles of the trailing bw x bw block (MFMA),
-//                      and L11, P copied into the band
+//                      and P = L21 copied into the band
 // and per panel one launch of hb2_fwd_kernel / hb2_bwd_kernel per substitution.  (A first version with
 // 32-column panels, a register Cholesky, scalar updates and 64-column substitutions cost 3.5 s per
 // 8 x 1024^2 gradient; these kernels 1.25-1.4 s)
@@ -151,25 +151,27 @@ __global__ __launch_bounds__(256) void hb_tw_vec_kernel(int mode, int bw, int n,
 
 constexpr int HB2_NB = 128;
 
-// Cholesky factor + inverse of the block in S (bcr_potrf_lds_body) and its three copies: L11 (this panel's
-// Cholesky tile, side buffer), L11^-1 and its transpose (kept per panel for the substitutions).
+// Cholesky factor + inverse of the block in S (bcr_potrf_lds_body); L11^-1 and its transpose are kept per panel:
+// the triangular solve of the panel, the next diagonal block and the substitutions all work with them, so the
+// Cholesky tile L11 itself is never stored (no kernel reads the diagonal blocks of L from the band).  Only the
+// nonzero triangle of each is written: Linv / LinvT are zero-filled once when the solver is allocated.
 __device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img, int k0, int npanel,
                                                  double* __restrict__ Linv, double* __restrict__ LinvT,
-                                                 double* __restrict__ L11, int* __restrict__ fail) {
+                                                 int* __restrict__ fail) {
     constexpr int MP = HB2_NB, ld = MP + 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    double* Lg = L11 + (size_t)img * MP * MP;
-    const bool bad = bcr_potrf_lds_body(S, MP, Lg, MP);
+    BCR_PROBE(4);
+    const bool bad = bcr_potrf_lds_body(S, MP);
+    BCR_PROBE(5);
     if (bad && lane == 0 && fail[img] == 0) fail[img] = k0 + 1;
     double* Li = Linv + ((size_t)img * npanel + k0 / MP) * MP * MP;
     double* LiT = LinvT + ((size_t)img * npanel + k0 / MP) * MP * MP;
     for (int e = tid; e < MP * MP; e += BCR_PT) {
         const int r = e % MP, c = e / MP;
-        Li[e] = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
-        LiT[e] = (c >= r) ? S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))] : 0.0;
-        if ((r >> 4) > (c >> 4)) Lg[e] = S[r + ld * c];          // strictly lower tiles of L
-        else if ((r >> 4) < (c >> 4)) Lg[e] = 0.0;               // (diagonal tiles were written by bcr_diag_tile)
+        if (r >= c) Li[e] = S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))];
+        if (c >= r) LiT[e] = S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))];
     }
+    BCR_PROBE(6);
 }
 
 // The dependent chain of the banded Cholesky in ONE launch per panel (one workgroup per problem): the diagonal
@@ -185,8 +187,7 @@ __device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img
 // array holds A(k, k-1), then P0, then D.
 __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restrict__ band, int bw, int n, int k0,
                                                            int npanel, double* __restrict__ Linv,
-                                                           double* __restrict__ LinvT, double* __restrict__ L11,
-                                                           int* __restrict__ fail) {
+                                                           double* __restrict__ LinvT, int* __restrict__ fail) {
     extern __shared__ double S[];
     constexpr int MP = HB2_NB, ld = MP + 1;
     const int W = bw + 1;
@@ -213,9 +214,10 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
             }
         }
         __syncthreads();
-        hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, L11, fail);
+        hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, fail);
         return;
     }
+    BCR_PROBE(0);
     // Every global operand is requested here, before anything waits: A(k, k-1) (32 entries per thread), this wave's
     // tiles of D and its rows of Linv(k-1) land together after one memory latency.
     // A(k0 + r, k0 - 128 + c), e = r + 128 c
@@ -242,10 +244,19 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
             lb[k4] = (k4 < 4 * (jw + 1)) ? Lp[(16 * jw + lr) + (size_t)MP * kq] : 0.0;
         }
     }
+    // D(r, c), r >= c, e = r + 128 c: whole columns of the band (the MFMA accumulator layout would gather 16 lines
+    // per load); added to -P0 P0^T in LDS afterwards
+    double dl[MP * MP / BCR_PT];
+#pragma unroll
+    for (int i = 0; i < MP * MP / BCR_PT; ++i) {
+        const int e = tid + i * BCR_PT, r = e % MP, c = e / MP;
+        double x = (r == c) ? 1.0 : 0.0;   // identity padding past the end of the matrix
+        if (r >= c && k0 + r < n) x = (r - c <= bw) ? Bd[r + (size_t)(W - 1) * c] : 0.0;
+        dl[i] = x;
+    }
     // lower 16x16 tiles of D, dealt round-robin over the 8 waves: tile t -> (I, J), I >= J
     constexpr int NTRI = NT * (NT + 1) / 2, TPW = (NTRI + BCR_PT / 64 - 1) / (BCR_PT / 64);
     int tI[TPW], tJ[TPW];
-    bcr_d4 dacc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         int t = wave + (BCR_PT / 64) * q, a = 0;
@@ -253,15 +264,6 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
         if (!have) t = 0;
         while (t > a) { t -= a + 1; ++a; }
         tI[q] = have ? a : -1; tJ[q] = t;
-        // D(R, C), R = 16 I + lk + 4 g, C = 16 J + lr
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int R = 16 * a + lk + 4 * g, C = 16 * t + lr;
-            const int lo = R < C ? R : C, hi = R < C ? C : R;
-            double x = (R == C) ? 1.0 : 0.0;   // identity padding past the end of the matrix
-            if (k0 + hi < n) x = (hi - lo <= bw) ? Bd[hi + (size_t)(W - 1) * lo] : 0.0;
-            dacc[q][g] = have ? x : 0.0;
-        }
     }
 #pragma unroll
     for (int i = 0; i < MP * MP / BCR_PT; ++i) {
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
         S[(e % MP) + ld * (e / MP)] = av[i];
     }
     __syncthreads();
+    BCR_PROBE(1);
     // P0 tile (i, jw) = sum over k-blocks kb <= jw of A(i, kb) Linv(jw, kb)^T for the 8 row tiles i
     {
         bcr_d4 acc[NT];
@@ -289,9 +292,12 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
             for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * jw + lr)] = acc[i][g];
     }
     __syncthreads();
-    // D tile (I, J) -= sum_k P0(16 I + r, k) P0(16 J + c, k)
+    BCR_PROBE(2);
+    // -P0 P0^T, tile (I, J): sum_k P0(16 I + r, k) P0(16 J + c, k)
+    bcr_d4 dacc[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
+        dacc[q] = bcr_d4{0.0, 0.0, 0.0, 0.0};
         if (tI[q] < 0) continue;
         const int ra = 16 * tI[q] + lr, rb = 16 * tJ[q] + lr;
         bcr_d4 acc = dacc[q];
@@ -307,14 +313,20 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
     for (int q = 0; q < TPW; ++q) {
         if (tI[q] < 0) continue;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int R = 16 * tI[q] + lk + 4 * g, C = 16 * tJ[q] + lr;
-            S[R + ld * C] = dacc[q][g];
-            if (tI[q] != tJ[q]) S[C + ld * R] = dacc[q][g];   // the upper triangle mirrors the lower
+        for (int g = 0; g < 4; ++g) S[(16 * tI[q] + lk + 4 * g) + ld * (16 * tJ[q] + lr)] = dacc[q][g];
+    }
+    __syncthreads();
+    BCR_PROBE(3);
+    // D = A(k, k) - P0 P0^T: the owner of (r, c), r >= c, adds the band entry
+#pragma unroll
+    for (int i = 0; i < MP * MP / BCR_PT; ++i) {
+        const int e = tid + i * BCR_PT, r = e % MP, c = e / MP;
+        if (r >= c) {
+            S[r + ld * c] += dl[i];   // (the Cholesky reads the lower triangle only)
         }
     }
     __syncthreads();
-    hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, L11, fail);
+    hb2_potrf_finish(S, img, k0, npanel, Linv, LinvT, fail);
 }
 
 // 64 x 32 chunk of the band as an MFMA operand: rows R0 + (tid & 63), columns K0 + (tid >> 6) + 4 i.
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
 //   part 0  the three tiles of the next panel's diagonal block;
 //   part 1  what the next panel's hb2_trsm_kernel and first update read or overwrite: the rest of the first
 //           128-column block (tiles (ta, 0), (ta, 1), ta >= 2) and the tiles (2,2), (3,2), (3,3) of the diagonal
-//           block after next; its workgroups also copy the finished panel (L11, and P = L21) into the band, which
-//           only the substitutions read -- they are done before the side buffers are reused two panels later;
+//           block after next; its workgroups also copy a finished panel P = L21 into the band, which only the
+//           substitutions read;
 //   part 2  everything else (tb >= 2), which only has to precede the same tiles' update by the next panel;
 //   part 5  no tile: the copies only.
 // Which launches a panel gets and on which streams: HbBandSolver::factor_problems (Cholesky; part 0 only for the last
@@ -423,8 +435,8 @@ __host__ __device__ inline int hb2_update_tiles(int nt, int part) {
 }
 __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void hb2_update_kernel(double* __restrict__ band, int bw, int n, int k0,
                                                           const double* __restrict__ P, int bwp, int part, int nprob,
-                                                          const double* __restrict__ PB, const double* __restrict__ cpL11,
-                                                          const double* __restrict__ cpP, int cpk0) {
+                                                          const double* __restrict__ PB, const double* __restrict__ cpP,
+                                                          int cpk0) {
     __shared__ double lds[BG_LDS];
     const int W = bw + 1;
     const int img = (int)(blockIdx.x % (unsigned)nprob), tid = threadIdx.x;
@@ -455,44 +467,28 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
         ta = a + 2; tb = t + 2;
     }
     const int base = k0 + HB2_NB;
-    // Copies of a finished panel (the one that starts at column cpk0: this panel, or an earlier one whose band
-    // entries were still being read) into the band -- only the substitutions read them -- off the critical path of
-    // the next panel's Cholesky: item 0 = L11, item 1 + t = rows [64 t, 64 t + 64) of L21, dealt round-robin over
-    // the workgroups of the launch.  Explicit batches of 16 loads, then the stores: a rolled copy loop pays one
-    // memory latency per iteration.
+    // Copy of a finished panel P = L21 (the one that starts at column cpk0: this panel, or an earlier one whose band
+    // entries were still being read) into the band -- only the substitutions read it -- off the critical path of the
+    // next panel's Cholesky: rows [64 t, 64 t + 64) of the panel are item t, dealt round-robin over the workgroups
+    // of the launch.  Explicit batches of 16 loads, then the stores: a rolled copy loop pays one memory latency per
+    // iteration.  (The diagonal blocks of L are not stored: no kernel reads them.)
     if (cpP) {
         const int cbase = cpk0 + HB2_NB;
         const double* Pc = cpP + (size_t)img * bwp * HB2_NB;
-        for (int item = bx; item < 1 + nt; item += gx) {
-            if (item == 0) {
-                if (!cpL11) continue;   // LU path: the diagonal block of L is the identity
-                const double* Lg = cpL11 + (size_t)img * HB2_NB * HB2_NB;
-                for (int e0 = tid; e0 < HB2_NB * HB2_NB; e0 += 16 * BG_T) {
-                    double v[16];
+        for (int tc = bx; tc < nt; tc += gx) {
+            if (cbase + 64 * tc >= n) continue;
+            for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
+                double v[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = Lg[e0 + i * BG_T];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int e = e0 + i * BG_T, r = e % HB2_NB, c = e / HB2_NB;
-                        if (r >= c && cpk0 + r < n && r - c <= bw) Bi[(size_t)(cpk0 + c) * W + (r - c)] = v[i];
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int e = e0 + i * BG_T;
+                    v[i] = Pc[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
                 }
-            } else {
-                const int tc = item - 1;
-                if (cbase + 64 * tc >= n) continue;
-                for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
-                    double v[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int e = e0 + i * BG_T;
-                        v[i] = Pc[64 * tc + (e & 63) + (size_t)bwp * (e >> 6)];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
-                        const int R = cbase + rr, K = cpk0 + c;
-                        if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int e = e0 + i * BG_T, rr = 64 * tc + (e & 63), c = e >> 6;
+                    const int R = cbase + rr, K = cpk0 + c;
+                    if (R < n && K < n && R - K <= bw) Bi[(size_t)K * W + (R - K)] = v[i];
                 }
             }
         }

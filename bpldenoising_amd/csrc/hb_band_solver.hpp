@@ -44,7 +44,7 @@ struct HbBandSolver {
     // device memory
     double* band = nullptr;      // [O*sides][np][bw+1]
     double* mid = nullptr;       // [O][nm][bw+1]
-    double* buf = nullptr;       // side problems: Linv | LinvT | L11 x2 | P
+    double* buf = nullptr;       // side problems: Linv | LinvT | P x2
     double* bufm = nullptr;      // middle problems
     double* vec = nullptr;       // twisted solve: vs | ys | xs ([O*2][np] each) | vm | ym | xm ([O][nm] each)
     int* fail = nullptr;         // [O*sides + O]
@@ -58,11 +58,11 @@ struct HbBandSolver {
 
     struct Bufs {
         int npanel;
-        double *Linv, *LinvT, *L11, *P;
+        double *Linv, *LinvT, *P;
     };
     static size_t bufs_doubles(int nprob, int ncol, int bw) {
         const size_t npanel = (size_t)(ncol + HB2_NB - 1) / HB2_NB, bwp = (size_t)(bw + 63) / 64 * 64;
-        return (size_t)nprob * ((2 * npanel + 3) * HB2_NB * HB2_NB + 3 * bwp * HB2_NB);
+        return (size_t)nprob * (2 * npanel * HB2_NB * HB2_NB + 2 * bwp * HB2_NB);
     }
     static Bufs carve(double* base, int nprob, int ncol) {
         Bufs b;
@@ -70,8 +70,7 @@ struct HbBandSolver {
         const size_t blk = (size_t)nprob * HB2_NB * HB2_NB;
         b.Linv = base;
         b.LinvT = base + blk * b.npanel;
-        b.L11 = b.LinvT + blk * b.npanel;   // three buffers (panel index mod 3)
-        b.P = b.L11 + 3 * blk;              // three buffers of nprob * bwp * 128 doubles
+        b.P = b.LinvT + blk * b.npanel;     // two buffers of nprob * bwp * 128 doubles (panel parity)
         return b;
     }
 
@@ -118,10 +117,13 @@ struct HbBandSolver {
         single_stream = e1 && e1[0] == '1';
         HBCHK(hipMalloc((void**)&band, (size_t)O * sides * np * W * sizeof(double)));
         HBCHK(hipMalloc((void**)&buf, bufs_doubles(O * sides, twisted ? m : n, bw) * sizeof(double)));
+        // hb3_chain_kernel writes only the nonzero triangles of L11^-1 and L11^-T
+        HBCHK(hipMemsetAsync(buf, 0, bufs_doubles(O * sides, twisted ? m : n, bw) * sizeof(double), stream));
         HBCHK(hipMalloc((void**)&fail, (size_t)O * 3 * sizeof(int)));
         if (twisted) {
             HBCHK(hipMalloc((void**)&mid, (size_t)O * nm * W * sizeof(double)));
             HBCHK(hipMalloc((void**)&bufm, bufs_doubles(O, nm, bw) * sizeof(double)));
+            HBCHK(hipMemsetAsync(bufm, 0, bufs_doubles(O, nm, bw) * sizeof(double), stream));
             HBCHK(hipMalloc((void**)&vec, (size_t)O * (6 * (size_t)np + 3 * (size_t)nm) * sizeof(double)));
         }
         HBCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hb3_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -161,36 +163,24 @@ struct HbBandSolver {
     //   stream3       U2(k) = update part 2 (the bulk, block columns >= k+2), after T(k), lowest priority.
     // C(k) needs U1(k-2) (and through it everything older); U1(k) needs U2(k-1) (same tiles); the rest is stream order.
     // So the triangular solve and both updates of panel k overlap with C(k+1).  Diagonal block k+1 is not updated in
-    // the band (C(k+1) does it in LDS) except behind the last panel, where part 0 runs.  Side buffers L11 and P
-    // rotate over three slots: slot k is read until U1(k+1)'s copies, rewritten by C(k+3) / T(k+3).
+    // the band (C(k+1) does it in LDS) except behind the last panel, where part 0 runs.  The panel buffer P
+    // alternates by panel parity: slot k is read until U1(k+1)'s copies, rewritten by T(k+2) behind them.
     int factor_problems(double* B, int nprob, int nrow, int nelim, const Bufs& hb, int* d_fail) {
         const int nt = (bw + 63) / 64, bwp = nt * 64;
         const int g0 = hb2_update_tiles(nt, 0), g1 = hb2_update_tiles(nt, 1), g2 = hb2_update_tiles(nt, 2);
         hipStream_t sA = single_stream ? stream : stream2, sB = single_stream ? stream : stream3;
-        const size_t blk = (size_t)nprob * HB2_NB * HB2_NB, pblk = (size_t)nprob * bwp * HB2_NB;
+        const size_t pblk = (size_t)nprob * bwp * HB2_NB;
         const double* nul = nullptr;
-        int k = 0, klast = -1;
+        int k = 0;
+        const double* Plast = nul;   // the newest panel, not yet copied into the band
+        int k0last = 0;
         for (int k0 = 0; k0 < nelim; k0 += HB2_NB, ++k) {
-            double* L11p = hb.L11 + (size_t)(k % 3) * blk;
-            double* Pp = hb.P + (size_t)(k % 3) * pblk;
-            const double* L11q = k > 0 ? hb.L11 + (size_t)((k - 1) % 3) * blk : nul;
-            const double* Pq = k > 0 ? hb.P + (size_t)((k - 1) % 3) * pblk : nul;
+            double* Pp = hb.P + (size_t)(k & 1) * pblk;
             const bool last = k0 + HB2_NB >= nelim;
             if (k >= 2 && !single_stream) HBCHK(hipStreamWaitEvent(stream, ev1[k & 1], 0));   // U1(k-2)
             hipLaunchKernelGGL(hb3_chain_kernel, dim3(nprob), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, B, bw, nrow, k0,
-                               hb.npanel, hb.Linv, hb.LinvT, L11p, d_fail);
-            klast = k;
-            if (k0 + HB2_NB >= nrow) {   // nothing below: only the copies are left (this panel's follow the loop)
-                if (k >= 1) {
-                    if (!single_stream) {
-                        HBCHK(hipEventRecord(ev[0], stream));
-                        HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
-                    }
-                    hipLaunchKernelGGL(hb2_update_kernel, dim3((1 + nt) * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, nul, bwp, 5, nprob,
-                                       nul, L11q, Pq, k0 - HB2_NB);
-                }
-                break;
-            }
+                               hb.npanel, hb.Linv, hb.LinvT, d_fail);
+            if (k0 + HB2_NB >= nrow) break;   // nothing below this panel
             if (!single_stream) {
                 HBCHK(hipEventRecord(ev[0], stream));
                 HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
@@ -203,26 +193,26 @@ struct HbBandSolver {
             }
             if (last)   // no chain kernel follows: the next diagonal block is updated in the band
                 hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 0,
-                                   nprob, nul, nul, nul, 0);
+                                   nprob, nul, nul, 0);
             if (k >= 1 && !single_stream && g2 > 0) HBCHK(hipStreamWaitEvent(sA, ev2, 0));     // U2(k-1)
             hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 1, nprob,
-                               nul, L11q, Pq, k0 - HB2_NB);
+                               nul, Plast, k0last);
+            Plast = Pp; k0last = k0;
             if (!single_stream) HBCHK(hipEventRecord(ev1[k & 1], sA));
             if (g2 > 0) {
                 hipLaunchKernelGGL(hb2_update_kernel, dim3(g2 * nprob), dim3(BG_T), 0, sB, B, bw, nrow, k0, (const double*)Pp, bwp, 2,
-                                   nprob, nul, nul, nul, 0);
+                                   nprob, nul, nul, 0);
                 if (!single_stream) HBCHK(hipEventRecord(ev2, sB));
             }
         }
-        if (klast >= 0) {   // the last panel's copies (its L11; its P when rows lie below it)
-            const int k0 = klast * HB2_NB;
+        if (Plast) {   // the newest panel's copy (every chain kernel that read its band entries is behind sA's last wait,
+                       // or is the last launch of the main stream: wait for it)
             if (!single_stream) {
                 HBCHK(hipEventRecord(ev[0], stream));
                 HBCHK(hipStreamWaitEvent(sA, ev[0], 0));
             }
-            hipLaunchKernelGGL(hb2_update_kernel, dim3((1 + nt) * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, nul, bwp, 5, nprob, nul,
-                               (const double*)(hb.L11 + (size_t)(klast % 3) * blk),
-                               (const double*)(hb.P + (size_t)(klast % 3) * pblk), k0);
+            hipLaunchKernelGGL(hb2_update_kernel, dim3(nt * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0last, nul, bwp, 5, nprob, nul, Plast,
+                               k0last);
         }
         if (!single_stream) {   // join: both side streams are complete before the caller continues
             HBCHK(hipEventRecord(ev1[0], sA));
@@ -275,6 +265,11 @@ struct HbBandSolver {
     }
 
     // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim)
+    // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim): one launch per block of
+    // 128 columns.  (Groups of four blocks per launch -- every workgroup solving the 512 x 512 triangle of the group
+    // redundantly, 14 operand blocks streamed through its registers, then applying it to its own rows -- were built and
+    // measured: 10 us (forward) and 20 us (backward) per block against 7-9 us here.  One CU streams about 50 GB/s,
+    // so what a block needs has to stay spread over 9 CUs, 256 KB each, as these launches do.)
     void fwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* x, double* y) {
         const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
         for (int k0 = 0; k0 < nelim; k0 += HB2_NB)

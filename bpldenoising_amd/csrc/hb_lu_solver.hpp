@@ -205,15 +205,13 @@ struct HbLuSolver {
                 if (gs[part] <= 0) continue;
                 // lower band (by columns): A(R, C) -= sum_k P(R, k) Q(C, k); no copies (the dense panels are kept)
                 hipLaunchKernelGGL(hb2_update_kernel, dim3(gs[part] * O), dim3(BG_T), 0, stream, bandL, bw, n, k0,
-                                   (const double*)P(k0), bwp, part == 1 ? 3 : part, O, (const double*)Q(), (const double*)nullptr,
-                                   (const double*)nullptr, 0);
+                                   (const double*)P(k0), bwp, part == 1 ? 3 : part, O, (const double*)Q(), (const double*)nullptr, 0);
             }
             for (int part = 0; part < 3; ++part) {
                 if (gs[part] <= 0) continue;
                 // upper band (by rows = lower band of A^T): A^T(C, R) -= sum_k Q(C, k) P(R, k); no copies (U12 = A12 stays)
                 hipLaunchKernelGGL(hb2_update_kernel, dim3(gs[part] * O), dim3(BG_T), 0, stream, bandU, bw, n, k0,
-                                   (const double*)Q(), bwp, part == 1 ? 3 : part, O, (const double*)P(k0), (const double*)nullptr,
-                                   (const double*)nullptr, 0);
+                                   (const double*)Q(), bwp, part == 1 ? 3 : part, O, (const double*)P(k0), (const double*)nullptr, 0);
             }
         }
         hipLaunchKernelGGL(hb_fail_merge_kernel, dim3((O + 63) / 64), dim3(64), 0, stream, fail, (const int*)nullptr, 1, O, d_fail_out);

@@ -171,6 +171,9 @@ int main() {
     ok &= run_case(256, 40, {0, 1, 2, 19, 20, 21, 40}, false, 1, true);
     ok &= run_case(300, 150, {0, 1, 149, 150}, true, 1, false);    // TV wide-image shape, not twisted
     ok &= run_case(4000, 200, {0, 1, 199, 200}, true, 2, false);   // twisted
+    ok &= run_case(1501, 151, {0, 1, 150, 151}, true, 2, false);   // odd bandwidth and order: 8-byte loads in the blocked substitutions
+    ok &= run_case(1100, 150, {0, 1, 149, 150}, true, 3, false);   // not twisted, two groups of four blocks + a ragged tail
+    ok &= run_case(5000, 300, {0, 1, 299, 300}, true, 8, false);   // eight problems per launch (one per XCD), three tile rows
     printf(ok ? "all ok\n" : "FAILURES\n");
     return ok ? 0 : 1;
 }

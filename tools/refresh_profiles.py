@@ -56,7 +56,7 @@ def aggregate(d):
                 nm = short(r["Kernel_Name"])
                 if nm.startswith("hb2_update"):   # the parts of the trailing update differ by their grid only
                     try:
-                        nm += "[%d wg]" % (int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+                        nm += "[%s wg]" % (int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)))))
                     except (KeyError, ValueError):
                         pass
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm))
