@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--evaluate", action="store_true", help="time full evaluate (loss + adjoint gradient + all-reduce)")
     ap.add_argument("--tile-iters", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--f32", action="store_true",
+                    help="opt-in single-precision PDHG (bpltv_create dtype = 32): narrower than the reference's Float64, "
+                         "never the headline; the line then says dtype f32 and counts 28/32 B per pixel-iteration")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chains", type=int, default=0, help="independent launch chains (0 = library default)")
@@ -253,7 +256,7 @@ def main():
         kw["chains"] = args.chains
     gloo = world > 1 and args.backend != "nccl"
     if O_local > 0:
-        solver = TVSolver(M, N, O_local, device=local_rank)
+        solver = TVSolver(M, N, O_local, device=local_rank, dtype=32 if args.f32 else 64)
         t_ub = torch.from_numpy(ub).cuda()
         t_f = torch.from_numpy(f).cuda()
         torch.cuda.synchronize()
@@ -346,14 +349,14 @@ def main():
         out = {
             "metric": "PDHG iters/sec (batched 128x128 images)",
             "value": value,
-            "unit": "PDHG iterations/s of a %dx%dx%d f64 batch%s" % (
-                args.images, N, M, " per GPU, summed over GPUs" if args.scaling == "weak" and world > 1 else ""),
+            "unit": "PDHG iterations/s of a %dx%dx%d %s batch%s" % (
+                args.images, N, M, "f32 (opt-in, narrower than the reference)" if args.f32 else "f64", " per GPU, summed over GPUs" if args.scaling == "weak" and world > 1 else ""),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * T / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": data_label,
-            "config": {"workload": "%dx%dx%d f64 batch, %s alpha, %d PDHG iterations per step (%s)" % (
-                           args.images, N, M, "per-pixel" if args.alpha_map else "scalar", args.iters,
+            "dtype": "f32" if args.f32 else "f64", "data": data_label,
+            "config": {"workload": "%dx%dx%d %s batch, %s alpha, %d PDHG iterations per step (%s)" % (
+                           args.images, N, M, "f32" if args.f32 else "f64", "per-pixel" if args.alpha_map else "scalar", args.iters,
                            "evaluate: loss + adjoint gradient + all-reduce" if args.evaluate else "denoise"),
                        "images_per_gpu": O_local, "tile_iters": st["tile_iters"], "tiles_per_launch": st["tiles"],
                        "launches_per_step": st["launches"], "hipgraph": bool(st["graph_used"]),

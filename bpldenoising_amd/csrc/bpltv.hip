@@ -38,18 +38,25 @@ struct Variant {
     const void* func;  // kernel symbol, for hipGraphAddKernelNode
     size_t lds;
     const char* name;
+    // the single-precision instantiation (handles created with dtype = 32)
+    void (*launch32)(const PdhgArgs&, int grid, hipStream_t);
+    const void* func32;
+    size_t lds32;
 };
 
-template <int PI, int PJ, int TI, int TJ>
+template <typename T, int PI, int PJ, int TI, int TJ>
 void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
-    constexpr size_t lds = pdhg_lds_bytes(PI * TI, PJ * TJ);
-    hipLaunchKernelGGL((pdhg_tile_kernel<PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
+    constexpr size_t lds = pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(T));
+    hipLaunchKernelGGL((pdhg_tile_kernel<T, PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
 }
 
 #define VAR(PI, PJ, TI, TJ)                                                                    \
-    { PI * TI, PJ * TJ, TI * TJ, &launch_variant<PI, PJ, TI, TJ>,                               \
-      reinterpret_cast<const void*>(&pdhg_tile_kernel<PI, PJ, TI, TJ>),                         \
-      pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr" }
+    { PI * TI, PJ * TJ, TI * TJ, &launch_variant<double, PI, PJ, TI, TJ>,                       \
+      reinterpret_cast<const void*>(&pdhg_tile_kernel<double, PI, PJ, TI, TJ>),                 \
+      pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr",                    \
+      &launch_variant<float, PI, PJ, TI, TJ>,                                                   \
+      reinterpret_cast<const void*>(&pdhg_tile_kernel<float, PI, PJ, TI, TJ>),                  \
+      pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(float)) }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
@@ -131,6 +138,15 @@ struct bpltv_handle {
     double* d_perimg = nullptr;   // [O] cost per image / gap per image
     double* d_scalar = nullptr;   // [4]
     std::map<TabKey, double*> tabs;
+    // dtype = 32 (opt-in): float twins of everything pdhg_tile_kernel reads and writes; the result is widened into
+    // the double state buffers after the solve, so that loss, gap, adjoint and the copies out are the f64 code
+    int dtype = 64;
+    float* f32_state[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    size_t f32_state_cap = 0;      // images
+    float *f32_f = nullptr, *f32_alpha = nullptr;
+    size_t f32_alpha_cap = 0;
+    bool f32_f_valid = false;
+    std::map<TabKey, float*> tabs32;
     std::map<GraphKey, std::vector<hipGraphExec_t>> graphs;  // one exec per chain
     std::vector<hipStream_t> chain_streams;
     std::vector<hipEvent_t> chain_events;
@@ -245,6 +261,78 @@ int get_table(bpltv_t* h, const bpltv_params& p, double** out, double L2 = 8.0) 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->tabs[k] = d;
     *out = d;
+    return BPLTV_OK;
+}
+
+// ---- dtype = 32: float twins of the PDHG kernel's operands -------------------------------------------------------
+void cvt_to_f32(bpltv_t* h, const double* src, float* dst, size_t n) {
+    const unsigned nb = (unsigned)std::min<size_t>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(nb), dim3(256), 0, h->stream, src, dst, n);
+}
+void cvt_to_f64(bpltv_t* h, const float* src, double* dst, size_t n) {
+    const unsigned nb = (unsigned)std::min<size_t>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL(cvt_f32_f64_kernel, dim3(nb), dim3(256), 0, h->stream, src, dst, n);
+}
+void drop_graphs(bpltv_t* h);
+// step table rounded to float (the oracle's bplo_pdhg_f32 rounds the same f64 table)
+int get_table32(bpltv_t* h, const bpltv_params& p, float** out) {
+    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, 8.0};
+    auto it = h->tabs32.find(k);
+    if (it != h->tabs32.end()) {
+        *out = it->second;
+        return BPLTV_OK;
+    }
+    std::vector<double> tab;
+    fill_table(k, tab);
+    std::vector<float> t32(tab.begin(), tab.end());
+    float* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, t32.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpyAsync(d, t32.data(), t32.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->tabs32[k] = d;
+    *out = d;
+    return BPLTV_OK;
+}
+// buffers for the current solve context (cur_nimg images) and fresh float copies of f and of the parameter
+int f32_prepare(bpltv_t* h) {
+    if (h->f32_state_cap < (size_t)h->cur_nimg) {
+        drop_graphs(h);   // captured kernels hold the old pointers
+        for (int s = 0; s < 2; ++s)
+            for (int c = 0; c < 3; ++c) {
+                if (h->f32_state[s][c]) HIPCHK(h, hipFree(h->f32_state[s][c]));
+                h->f32_state[s][c] = nullptr;
+                HIPCHK(h, hipMalloc((void**)&h->f32_state[s][c], (size_t)h->cur_nimg * h->npx * sizeof(float)));
+            }
+        h->f32_state_cap = (size_t)h->cur_nimg;
+    }
+    if (!h->f32_f) HIPCHK(h, hipMalloc((void**)&h->f32_f, h->tot * sizeof(float)));
+    if (!h->f32_f_valid) {
+        cvt_to_f32(h, h->d_f, h->f32_f, h->tot);
+        h->f32_f_valid = true;
+    }
+    if (h->f32_alpha_cap < h->alpha_cap) {
+        drop_graphs(h);
+        if (h->f32_alpha) HIPCHK(h, hipFree(h->f32_alpha));
+        h->f32_alpha = nullptr;
+        HIPCHK(h, hipMalloc((void**)&h->f32_alpha, h->alpha_cap * sizeof(float)));
+        h->f32_alpha_cap = h->alpha_cap;
+    }
+    cvt_to_f32(h, h->d_alpha, h->f32_alpha, h->alpha_cap);
+    HIPCHK(h, hipGetLastError());
+    return BPLTV_OK;
+}
+// operand pointers of the PDHG kernel for this handle's dtype (float arrays travel in PdhgArgs' double* fields)
+inline double* pdhg_state(bpltv_t* h, int set, int c) {
+    return h->dtype == 32 ? reinterpret_cast<double*>(h->f32_state[set][c]) : h->cur_state[set][c];
+}
+inline const double* pdhg_f(bpltv_t* h) { return h->dtype == 32 ? reinterpret_cast<const double*>(h->f32_f) : h->d_f; }
+inline const double* pdhg_alpha(bpltv_t* h) {
+    return h->dtype == 32 ? reinterpret_cast<const double*>(h->f32_alpha) : h->d_alpha;
+}
+// the solve's result (set `buf`) widened into the double state buffers
+int f32_widen(bpltv_t* h, int buf) {
+    for (int c = 0; c < 3; ++c) cvt_to_f64(h, h->f32_state[buf][c], h->cur_state[buf][c], (size_t)h->cur_nimg * h->npx);
+    HIPCHK(h, hipGetLastError());
     return BPLTV_OK;
 }
 
@@ -366,7 +454,7 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         int cur = 0;
         for (int it = 0; it < p.maxiter; it += pl.T) {
             PdhgArgs a;
-            a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
+            a.f = pdhg_f(h); a.alpha = pdhg_alpha(h); a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
             a.M = h->M; a.N = h->N; a.O = h->cur_nimg;
             a.Odata = h->O; a.astride = h->cur_astride;
@@ -377,17 +465,17 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
 #endif
             const int nxt = (it == 0) ? 0 : 1 - cur;
             a.first = (it == 0) ? 1 : 0;
-            a.xin = h->cur_state[cur][0]; a.y1in = h->cur_state[cur][1]; a.y2in = h->cur_state[cur][2];
-            a.xout = h->cur_state[nxt][0]; a.y1out = h->cur_state[nxt][1]; a.y2out = h->cur_state[nxt][2];
+            a.xin = pdhg_state(h, cur, 0); a.y1in = pdhg_state(h, cur, 1); a.y2in = pdhg_state(h, cur, 2);
+            a.xout = pdhg_state(h, nxt, 0); a.y1out = pdhg_state(h, nxt, 1); a.y2out = pdhg_state(h, nxt, 2);
             a.it0 = it;
             a.nit = std::min(pl.T, p.maxiter - it);
             void* kargs[] = {&a};
             hipKernelNodeParams kp;
             std::memset(&kp, 0, sizeof(kp));
-            kp.func = const_cast<void*>(V.func);
+            kp.func = const_cast<void*>(h->dtype == 32 ? V.func32 : V.func);
             kp.gridDim = dim3(tilesPerImg * (hi - lo));
             kp.blockDim = dim3(V.threads);
-            kp.sharedMemBytes = (unsigned)V.lds;
+            kp.sharedMemBytes = (unsigned)(h->dtype == 32 ? V.lds32 : V.lds);
             kp.kernelParams = kargs;
             kp.extra = nullptr;
             hipGraphNode_t node = nullptr;
@@ -420,8 +508,8 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
                  int* buf, int* launches) {
     const Variant& V = kVariants[pl.variant];
     PdhgArgs a;
-    a.f = h->d_f;
-    a.alpha = h->d_alpha;
+    a.f = pdhg_f(h);
+    a.alpha = pdhg_alpha(h);
     a.tab = d_tab;
     a.rho = p.rho;
     a.am = h->last_am;
@@ -438,11 +526,11 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         const int nit = std::min(pl.T, it1 - it);
         const int nxt = (it == 0) ? 0 : 1 - cur;
         a.first = (it == 0) ? 1 : 0;
-        a.xin = h->cur_state[cur][0]; a.y1in = h->cur_state[cur][1]; a.y2in = h->cur_state[cur][2];
-        a.xout = h->cur_state[nxt][0]; a.y1out = h->cur_state[nxt][1]; a.y2out = h->cur_state[nxt][2];
+        a.xin = pdhg_state(h, cur, 0); a.y1in = pdhg_state(h, cur, 1); a.y2in = pdhg_state(h, cur, 2);
+        a.xout = pdhg_state(h, nxt, 0); a.y1out = pdhg_state(h, nxt, 1); a.y2out = pdhg_state(h, nxt, 2);
         a.it0 = it;
         a.nit = nit;
-        V.launch(a, pl.grid, h->stream);
+        (h->dtype == 32 ? V.launch32 : V.launch)(a, pl.grid, h->stream);
         cur = nxt;
         ++*launches;
     }
@@ -481,7 +569,14 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     int rc = make_plan(h, p, &pl);
     if (rc) return rc;
     double* d_tab = nullptr;
-    rc = get_table(h, p, &d_tab);
+    if (h->dtype == 32) {
+        float* t32 = nullptr;
+        rc = get_table32(h, p, &t32);
+        if (!rc && p.maxiter > 0) rc = f32_prepare(h);
+        d_tab = reinterpret_cast<double*>(t32);
+    } else {
+        rc = get_table(h, p, &d_tab);
+    }
     if (rc) return rc;
     h->st.tile_iters = pl.T;
     h->st.tiles = pl.grid;
@@ -513,7 +608,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (!chunked) {
         bool done = false;
         if (p.use_graph) {
-            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)h->cur_state[0][0]};
+            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)pdhg_state(h, 0, 0)};
             auto it = h->graphs.find(key);
             const int nl = (p.maxiter + pl.T - 1) / pl.T;
             if (it == h->graphs.end() && h->graphs.size() >= 16) {  // bounded cache
@@ -562,6 +657,10 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             if (rc) return rc;
         }
         h->st.iterations = p.maxiter;
+        if (h->dtype == 32) {
+            rc = f32_widen(h, buf);
+            if (rc) return rc;
+        }
     } else {
         int it = 0;
         while (it < p.maxiter) {
@@ -570,6 +669,10 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             if (rc) return rc;
             it = it1;
             h->result_buf = buf;
+            if (h->dtype == 32) {   // the gap kernels read the double state
+                rc = f32_widen(h, buf);
+                if (rc) return rc;
+            }
             double gmax = 0.0;
             rc = compute_gap(h, nullptr, &gmax);
             if (rc) return rc;
@@ -588,7 +691,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->has_result = true;
     h->last_is_sr = false;
     const bool amap = (h->last_am == h->M && h->last_an == h->N) && !(h->M == 1 && h->N == 1);
-    h->st.bytes_per_px_iter = amap ? 64.0 : 56.0;
+    h->st.bytes_per_px_iter = (amap ? 64.0 : 56.0) * (h->dtype == 32 ? 0.5 : 1.0);
     h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->npx * h->cur_nimg * h->st.iterations;
     return BPLTV_OK;
 }
@@ -1356,7 +1459,7 @@ void multi_free(bpltv_t* h) {
 int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nshards, int dtype) {
     if (!out) return BPLTV_E_ARG;
     *out = nullptr;
-    if (M < 1 || N < 1 || O < 1 || dtype != 64 || !devices || nshards < 1) return BPLTV_E_ARG;
+    if (M < 1 || N < 1 || O < 1 || (dtype != 64 && dtype != 32) || !devices || nshards < 1) return BPLTV_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BPLTV_E_HIP;
     for (int k = 0; k < nshards; ++k)
@@ -1388,8 +1491,8 @@ int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nsh
     ms->d_all.assign(n, nullptr);
     h->st.ngpus = (int)distinct.size();
     h->st.shards = n;
-    int rc = multi_run(h, [ms, M, N](int k, bpltv_t*) -> int {
-        return bpltv_create(&ms->shard[k], M, N, ms->hi[k] - ms->lo[k], ms->dev[k], 64);
+    int rc = multi_run(h, [ms, M, N, dtype](int k, bpltv_t*) -> int {
+        return bpltv_create(&ms->shard[k], M, N, ms->hi[k] - ms->lo[k], ms->dev[k], dtype);
     });
     if (rc) return rc;
     if ((int)distinct.size() == n) {   // one rank per device: RCCL communicator of this process
@@ -1642,7 +1745,7 @@ int bpltv_default_params(bpltv_params* p) {
 int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     if (!out) return BPLTV_E_ARG;
     *out = nullptr;
-    if (M < 1 || N < 1 || O < 1 || dtype != 64) return BPLTV_E_ARG;
+    if (M < 1 || N < 1 || O < 1 || (dtype != 64 && dtype != 32)) return BPLTV_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BPLTV_E_HIP;
     if (device < 0) {
@@ -1651,7 +1754,7 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     if (device >= ndev) return BPLTV_E_ARG;
     bpltv_t* h = new (std::nothrow) bpltv_handle();
     if (!h) return BPLTV_E_NOMEM;
-    h->M = M; h->N = N; h->O = O; h->device = device;
+    h->M = M; h->N = N; h->O = O; h->device = device; h->dtype = dtype;
     h->npx = (size_t)M * N;
     h->tot = h->npx * O;
     std::memset(&h->st, 0, sizeof(h->st));
@@ -1676,9 +1779,12 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     HIPCHK(h, hipMalloc((void**)&h->d_perimg, (size_t)O * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_scalar, 4 * sizeof(double)));
     // LDS above 64 KB needs the opt-in attribute
-    for (const Variant& V : kVariants)
+    for (const Variant& V : kVariants) {
         if (V.lds > 64 * 1024)
             HIPCHK(h, hipFuncSetAttribute(V.func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds));
+        if (dtype == 32 && V.lds32 > 64 * 1024)
+            HIPCHK(h, hipFuncSetAttribute(V.func32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)V.lds32));
+    }
     return BPLTV_OK;
 }
 
@@ -1711,6 +1817,12 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto cs : h->chain_streams) (void)hipStreamDestroy(cs);
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
+    for (auto& kv : h->tabs32) (void)hipFree(kv.second);
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c)
+            if (h->f32_state[s][c]) (void)hipFree(h->f32_state[s][c]);
+    if (h->f32_f) (void)hipFree(h->f32_f);
+    if (h->f32_alpha) (void)hipFree(h->f32_alpha);
     void* ptrs[] = {h->d_ubar, h->d_f, h->d_alpha, h->d_partial, h->d_red, h->d_perimg, h->d_scalar, h->d_coef,
                     h->d_band4, h->d_bcr, h->d_L, h->d_invF, h->d_invB, h->d_L1, h->d_dump, h->d_Lm, h->d_spill, h->d_p, h->d_r, h->d_gpix, h->d_resn, h->d_fail, h->d_u2, h->d_ubar2};
     for (void* p : ptrs)
@@ -1747,6 +1859,7 @@ static int set_data_impl(bpltv_t* h, const double* ubar, const double* f, hipMem
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_data = true;
     h->has_result = false;
+    h->f32_f_valid = false;
     return BPLTV_OK;
 }
 

@@ -23,8 +23,8 @@ namespace bpltv {
 
 // LDS bytes of pdhg_tile_kernel for a region RI x RJ: y1 plane with a guard column, y2 plane with a
 // guard row, xbar plane with RI+1 pad cells.
-constexpr size_t pdhg_lds_bytes(int RI, int RJ) {
-    return sizeof(double) * ((size_t)RJ * (RI + 1) + (size_t)(RJ + 1) * RI + (size_t)RJ * RI + RI + 1);
+constexpr size_t pdhg_lds_bytes(int RI, int RJ, size_t word = sizeof(double)) {
+    return word * ((size_t)RJ * (RI + 1) + (size_t)(RJ + 1) * RI + (size_t)RJ * RI + RI + 1);
 }
 
 constexpr int TAB_STRIDE = 8;  // doubles per iteration row: tau, sigma, omega, 1/(1+tau), 1+omega, pad
@@ -115,7 +115,26 @@ __device__ __forceinline__ double rsqrt_nr(double n2) {
     return r;
 }
 
-template <int PI, int PJ, int TI, int TJ>
+// the same in single precision ("spec v2f"): three Newton steps from the classic 32-bit seed
+__device__ __forceinline__ float rsqrt_nr(float n2) {
+    const unsigned u = 0x5F375A86u - (__float_as_uint(n2) >> 1);
+    float r = __uint_as_float(u);
+    const float h = 0.5f * n2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t = r * r;
+        const float w = __builtin_fmaf(-h, t, 1.5f);
+        r = r * w;
+    }
+    return r;
+}
+__device__ __forceinline__ double pd_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float pd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// T = double: the reference's arithmetic.  T = float: the opt-in single-precision mode of bpltv_create(dtype = 32) --
+// the same operation sequence in f32 ("spec v2f": bplo_pdhg_f32 of the oracle), with state, f, alpha and the step
+// table held as float (the pointers of PdhgArgs then address float arrays): half the LDS and HBM bytes per pixel.
+template <typename T, int PI, int PJ, int TI, int TJ>
 __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     constexpr int RI = PI * TI, RJ = PJ * TJ;
     // LDS planes with guard cells so that the neighbour reads need no select:
@@ -125,10 +144,18 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     //        finite garbage (zeros); there the result is either masked by the image-border test or
     //        lies in the halo that is never written back
     constexpr int S1 = RI + 1;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sy1 = smem;                              // [RJ][S1]
-    double* sy2 = smem + RJ * S1;                    // [RJ+1][RI]
-    double* sxb = smem + RJ * S1 + (RJ + 1) * RI;    // [RJ][RI] + RI + 1
+    extern __shared__ __attribute__((aligned(16))) unsigned char pdhg_smem[];
+    T* smem = reinterpret_cast<T*>(pdhg_smem);
+    T* sy1 = smem;                              // [RJ][S1]
+    T* sy2 = smem + RJ * S1;                    // [RJ+1][RI]
+    T* sxb = smem + RJ * S1 + (RJ + 1) * RI;    // [RJ][RI] + RI + 1
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
 
     const int tid = threadIdx.x;
     const int ti = tid % TI, tj = tid / TI;
@@ -143,13 +170,13 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     const int M = A.M, N = A.N;
     const size_t base = (size_t)img * M * N;                 // state planes: one slot per solve image
     const size_t fbase = (size_t)(img % A.Odata) * M * N;    // dataset planes
-    const double* __restrict__ alpha = A.alpha + (size_t)(img / A.Odata) * A.astride;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)(img / A.Odata) * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
     const bool first = (A.first != 0) || (BPLTV_DBG(A) & 1);
 
     // ---- prologue: every global load is issued before the first use (one memory round trip).
     // Out-of-image pixels read a clamped in-image address and are zeroed afterwards.
-    double x[PJ][PI], y1[PJ][PI], y2[PJ][PI], f[PJ][PI], al[PJ][PI];
+    T x[PJ][PI], y1[PJ][PI], y2[PJ][PI], f[PJ][PI], al[PJ][PI];
     size_t gidx[PJ][PI], fidx[PJ][PI], aidx[PJ][PI];
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj)
@@ -175,13 +202,13 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
                 if (BPLTV_DBG(A) & 64) {  // experiment: non-temporal loads
-                    x[pj][pi] = __builtin_nontemporal_load(&A.xin[gidx[pj][pi]]);
-                    y1[pj][pi] = __builtin_nontemporal_load(&A.y1in[gidx[pj][pi]]);
-                    y2[pj][pi] = __builtin_nontemporal_load(&A.y2in[gidx[pj][pi]]);
+                    x[pj][pi] = __builtin_nontemporal_load(&Axin[gidx[pj][pi]]);
+                    y1[pj][pi] = __builtin_nontemporal_load(&Ay1in[gidx[pj][pi]]);
+                    y2[pj][pi] = __builtin_nontemporal_load(&Ay2in[gidx[pj][pi]]);
                 } else {
-                    x[pj][pi] = A.xin[gidx[pj][pi]];
-                    y1[pj][pi] = A.y1in[gidx[pj][pi]];
-                    y2[pj][pi] = A.y2in[gidx[pj][pi]];
+                    x[pj][pi] = Axin[gidx[pj][pi]];
+                    y1[pj][pi] = Ay1in[gidx[pj][pi]];
+                    y2[pj][pi] = Ay2in[gidx[pj][pi]];
                 }
             }
     }
@@ -189,7 +216,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            f[pj][pi] = A.f[fidx[pj][pi]];
+            f[pj][pi] = Af[fidx[pj][pi]];
             al[pj][pi] = alpha[aidx[pj][pi]];
         }
 #pragma unroll
@@ -200,21 +227,21 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             const bool in = (oi + li < M) && (oj + lj < N);
             if (first) {
                 x[pj][pi] = f[pj][pi];
-                y1[pj][pi] = 0.0;
-                y2[pj][pi] = 0.0;
+                y1[pj][pi] = T(0);
+                y2[pj][pi] = T(0);
             }
             if (!in) {
-                f[pj][pi] = 0.0; x[pj][pi] = 0.0; y1[pj][pi] = 0.0; y2[pj][pi] = 0.0; al[pj][pi] = 0.0;
+                f[pj][pi] = T(0); x[pj][pi] = T(0); y1[pj][pi] = T(0); y2[pj][pi] = T(0); al[pj][pi] = T(0);
             }
             sy1[lj * S1 + li + 1] = y1[pj][pi];
             sy2[(lj + 1) * RI + li] = y2[pj][pi];
         }
-    for (int e = threadIdx.x; e < RJ; e += TI * TJ) sy1[e * S1] = 0.0;
-    for (int e = threadIdx.x; e < RI; e += TI * TJ) sy2[e] = 0.0;
-    for (int e = threadIdx.x; e < RI + 1; e += TI * TJ) sxb[RI * RJ + e] = 0.0;
+    for (int e = threadIdx.x; e < RJ; e += TI * TJ) sy1[e * S1] = T(0);
+    for (int e = threadIdx.x; e < RI; e += TI * TJ) sy2[e] = T(0);
+    for (int e = threadIdx.x; e < RI + 1; e += TI * TJ) sxb[RI * RJ + e] = T(0);
     __syncthreads();
 
-    const double rho = A.rho;
+    const T rho = (T)A.rho;
     const int nit = (BPLTV_DBG(A) & 4) ? 0 : A.nit;
     // Neumann border without a select in the loop: at the last image row/column (and outside the
     // image) the "neighbour" read is redirected to the pixel's own xbar cell, so the forward
@@ -230,15 +257,15 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             n2[pj][pi] = l + (((oj + lj) < N - 1) ? RI : 0);
         }
     // step sizes of iteration `it`: scalar loads, issued one iteration ahead
-    const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * A.it0;
-    double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
+    T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
     for (int it = 0; it < nit; ++it) {
-        const double* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
-        const double ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
-        double xb[PJ][PI];
+        const T* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
+        const T ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        T xb[PJ][PI];
         // ---- primal step: x <- prox_{tau*fidelity}(x - tau * G^T y); over-relaxation.
         // LDS reads are unconditional (clamped index) and selected afterwards: one wait for all.
-        double y1m[PJ][PI], y2m[PJ][PI];
+        T y1m[PJ][PI], y2m[PJ][PI];
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
@@ -253,18 +280,18 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             for (int pi = 0; pi < PI; ++pi) {
                 const int li = ti + TI * pi, lj = tj + TJ * pj;
                 const int l = lj * RI + li;
-                const double div = (y1m[pj][pi] - y1[pj][pi]) + (y2m[pj][pi] - y2[pj][pi]);
-                const double tt = div - f[pj][pi];
-                const double xo = x[pj][pi];
-                const double xn = __builtin_fma(-tau, tt, xo) * inv1ptau;
-                const double b = __builtin_fma(-omega, xo, opw * xn);
+                const T div = (y1m[pj][pi] - y1[pj][pi]) + (y2m[pj][pi] - y2[pj][pi]);
+                const T tt = div - f[pj][pi];
+                const T xo = x[pj][pi];
+                const T xn = pd_fma(-tau, tt, xo) * inv1ptau;
+                const T b = pd_fma(-omega, xo, opw * xn);
                 x[pj][pi] = xn;
                 xb[pj][pi] = b;
                 sxb[l] = b;
             }
         __syncthreads();
         // ---- dual step: y <- proj_{|y_ij| <= alpha_ij}((y + sigma * G xbar) / (1 + sigma*rho/alpha))
-        double xp1[PJ][PI], xpM[PJ][PI];
+        T xp1[PJ][PI], xpM[PJ][PI];
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
@@ -272,26 +299,26 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 xp1[pj][pi] = sxb[n1[pj][pi]];
                 xpM[pj][pi] = sxb[n2[pj][pi]];
             }
-        double n2v[PJ][PI];
+        T n2v[PJ][PI];
         bool any_out = false;
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const double b = xb[pj][pi];
-                const double d1 = xp1[pj][pi] - b;
-                const double d2 = xpM[pj][pi] - b;
-                const double a = al[pj][pi];
-                double y1n = __builtin_fma(sigma, d1, y1[pj][pi]);
-                double y2n = __builtin_fma(sigma, d2, y2[pj][pi]);
-                if (rho != 0.0) {
-                    const double den = 1.0 + sigma * rho / a;
+                const T b = xb[pj][pi];
+                const T d1 = xp1[pj][pi] - b;
+                const T d2 = xpM[pj][pi] - b;
+                const T a = al[pj][pi];
+                T y1n = pd_fma(sigma, d1, y1[pj][pi]);
+                T y2n = pd_fma(sigma, d2, y2[pj][pi]);
+                if (rho != T(0)) {
+                    const T den = T(1) + sigma * rho / a;
                     y1n = y1n / den;
                     y2n = y2n / den;
                 }
                 y1[pj][pi] = y1n;
                 y2[pj][pi] = y2n;
-                n2v[pj][pi] = __builtin_fma(y2n, y2n, y1n * y1n);
+                n2v[pj][pi] = pd_fma(y2n, y2n, y1n * y1n);
                 any_out |= n2v[pj][pi] > a * a;
             }
         // projection onto the alpha-ball.  One pixel per thread: a wave whose pixels all lie inside
@@ -302,8 +329,8 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
                 for (int pi = 0; pi < PI; ++pi) {
-                    const double a = al[pj][pi];
-                    const double v = a * rsqrt_nr(n2v[pj][pi]);
+                    const T a = al[pj][pi];
+                    const T v = a * rsqrt_nr(n2v[pj][pi]);
                     const bool outp = n2v[pj][pi] > a * a;
                     y1[pj][pi] = outp ? y1[pj][pi] * v : y1[pj][pi];
                     y2[pj][pi] = outp ? y2[pj][pi] * v : y2[pj][pi];
@@ -330,21 +357,21 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
             if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(BPLTV_DBG(A) & 2)) {
                 const size_t idx = base + gi + (size_t)M * gj;
                 if (BPLTV_DBG(A) & 16) {  // experiment: non-temporal stores
-                    __builtin_nontemporal_store(x[pj][pi], &A.xout[idx]);
-                    __builtin_nontemporal_store(y1[pj][pi], &A.y1out[idx]);
-                    __builtin_nontemporal_store(y2[pj][pi], &A.y2out[idx]);
+                    __builtin_nontemporal_store(x[pj][pi], &Axout[idx]);
+                    __builtin_nontemporal_store(y1[pj][pi], &Ay1out[idx]);
+                    __builtin_nontemporal_store(y2[pj][pi], &Ay2out[idx]);
                 } else if (!(BPLTV_DBG(A) & 32)) {
                     // write-through (sc1) stores: the state of this launch is read next by workgroups
                     // on other XCDs, so it has to reach memory anyway; writing through while the
                     // kernel still runs leaves no dirty L2 lines for the end-of-kernel release
                     // (-0.9 us per launch on MI355X, profiles/README.md)
-                    __hip_atomic_store(&A.xout[idx], x[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&A.y1out[idx], y1[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&A.y2out[idx], y2[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Axout[idx], x[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Ay1out[idx], y1[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Ay2out[idx], y2[pj][pi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    A.xout[idx] = x[pj][pi];
-                    A.y1out[idx] = y1[pj][pi];
-                    A.y2out[idx] = y2[pj][pi];
+                    Axout[idx] = x[pj][pi];
+                    Ay1out[idx] = y1[pj][pi];
+                    Ay2out[idx] = y2[pj][pi];
                 }
             }
         }
@@ -475,6 +502,14 @@ __global__ __launch_bounds__(256) void gap_final_kernel(const double* __restrict
         for (int k = 1; k < O; ++k) m = (gap[k] > m) ? gap[k] : m;
         gap_max[0] = m;
     }
+}
+
+// dtype = 32 handles: narrowing of the kernel's inputs, widening of its result.  grid-stride, block 256.
+__global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) dst[e] = (float)src[e];
+}
+__global__ __launch_bounds__(256) void cvt_f32_f64_kernel(const float* __restrict__ src, double* __restrict__ dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) dst[e] = (double)src[e];
 }
 
 // FwdGradientOp / adjoint for one M x N image (operator tests, A4).

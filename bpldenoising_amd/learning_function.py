@@ -69,17 +69,20 @@ class TVSolver:
     -- block-sharded over several GPUs behind the same handle (bpltv_create_multi / bpltv_create_sharded:
     one worker thread per device inside the library, one RCCL collective per evaluation)."""
 
-    def __init__(self, M, N, O, device=-1, ngpus=None, devices=None):
+    def __init__(self, M, N, O, device=-1, ngpus=None, devices=None, dtype=64):
+        """dtype: 64 = the reference's Float64 (default); 32 = opt-in single-precision PDHG iteration (include/bpltv.h,
+        bpltv_create) -- narrower than the reference, every array in and out stays float64."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.M, self.N, self.O = int(M), int(N), int(O)
+        self.dtype = int(dtype)
         if devices is not None:
             d = (C.c_int * len(devices))(*[int(x) for x in devices])
-            rc = self._lib.bpltv_create_sharded(C.byref(self._h), self.M, self.N, self.O, d, len(devices), 64)
+            rc = self._lib.bpltv_create_sharded(C.byref(self._h), self.M, self.N, self.O, d, len(devices), self.dtype)
         elif ngpus is not None:
-            rc = self._lib.bpltv_create_multi(C.byref(self._h), self.M, self.N, self.O, int(ngpus), 64)
+            rc = self._lib.bpltv_create_multi(C.byref(self._h), self.M, self.N, self.O, int(ngpus), self.dtype)
         else:
-            rc = self._lib.bpltv_create(C.byref(self._h), self.M, self.N, self.O, int(device), 64)
+            rc = self._lib.bpltv_create(C.byref(self._h), self.M, self.N, self.O, int(device), self.dtype)
         if rc:
             msg = self._lib.bpltv_last_error(self._h).decode() if self._h else "bpltv_create failed"
             if self._h:

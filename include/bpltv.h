@@ -127,7 +127,13 @@ typedef struct bpltv_stats {
 int bpltv_default_params(bpltv_params *p);
 
 /* Create a solver for O images of size M x N on HIP device `device` (-1 = current device).
- * dtype: 64 (Float64, the reference's arithmetic, src/TVLearningFunctionVec.jl:8-9). */
+ * dtype: 64 = Float64, the reference's arithmetic (src/TVLearningFunctionVec.jl:8-9) and what every parity claim
+ * refers to.  32 = opt-in: the PDHG iteration of the TV model (bpltv_denoise, bpltv_evaluate, bpltv_sweep) runs in
+ * single precision -- f, the parameter and the step table rounded to float, state in float, half the bytes per
+ * pixel-iteration -- and its result is widened to double; loss, duality gap, adjoint gradient, the sum-of-regularisers
+ * model and every array crossing this boundary stay Float64.  Narrower than the reference: u differs from the
+ * Float64 result by up to ~2e-5 absolute after 5000 iterations, and the gradient by ~1 %: the reference's active set
+ * |grad u| < 1e-12 (src/TVLearningFunctionVec.jl:110) does not survive float noise in u (tests/test_gpu_f32.py).  Other values: BPLTV_E_ARG. */
 int bpltv_create(bpltv_t **h, int M, int N, int O, int device, int dtype);
 /* The same over `ngpus` devices (0 = all visible; devices 0..ngpus-1) driven from one host thread -- the
  * form SURVEY section 8(b)/(e) specifies for the single Julia task of src/TRBox.jl:192-273.  Images

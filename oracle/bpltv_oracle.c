@@ -209,6 +209,98 @@ static void pdhg_image(int M, int N, const double *f, const double *alpha, int a
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * "spec v2f": the same recurrence in single precision, the checker of the opt-in dtype = 32 mode of the library
+ * (include/bpltv.h, bpltv_create).  Inputs f and alpha and the f64 step table are rounded to float once; every
+ * operation of pdhg_x_pass / pdhg_y_pass is repeated in float with fmaf; the projection uses three Newton steps
+ * from the 32-bit seed 0x5F375A86 (e -> 1.5 e^2 from < 3.5e-2: 1.8e-3, 4.7e-6, 3.3e-11 < 2^-24).  The result is
+ * widened to double.  Not a restatement of anything in the reference (which is Float64 only).
+ * ---------------------------------------------------------------------------------------- */
+static inline float rsqrt_nr_f(float n2)
+{
+    union { float f; uint32_t u; } c;
+    c.f = n2;
+    c.u = 0x5F375A86u - (c.u >> 1);
+    float r = c.f;
+    const float h = 0.5f * n2;
+    for (int k = 0; k < 3; ++k) {
+        float t = r * r;
+        float w = fmaf(-h, t, 1.5f);
+        r = r * w;
+    }
+    return r;
+}
+
+static inline float alpha_at_f(const float *alpha, int am, int an, int M, int N, int i, int j)
+{
+    if (am == 1 && an == 1) return alpha[0];
+    if (am == M && an == N) return alpha[i + (size_t)M * j];
+    return alpha[(int)(((long)i * am) / M) + (size_t)am * (int)(((long)j * an) / N)];
+}
+
+BPLO_API int bplo_pdhg_f32(int M, int N, int O, const double *f, const double *alpha, int am, int an,
+                           double rho_, double tau0, double sigma0, int accel, int maxiter, double *x_out)
+{
+    if (M < 1 || N < 1 || O < 0 || maxiter < 0) return 1;
+    const size_t n = (size_t)M * N, na = (size_t)am * an;
+    double *tab = (double *)malloc(sizeof(double) * 5 * (size_t)(maxiter > 0 ? maxiter : 1));
+    float *ff = (float *)malloc(n * sizeof(float)), *x = (float *)malloc(n * sizeof(float));
+    float *y1 = (float *)malloc(n * sizeof(float)), *y2 = (float *)malloc(n * sizeof(float));
+    float *xb = (float *)malloc(n * sizeof(float)), *al = (float *)malloc(na * sizeof(float));
+    int rc = 0;
+    if (!tab || !ff || !x || !y1 || !y2 || !xb || !al) {
+        rc = 2;
+    } else {
+        bplo_step_table(maxiter, tau0, sigma0, accel, tab);
+        for (size_t e = 0; e < na; ++e) al[e] = (float)alpha[e];
+        const float rho = (float)rho_;
+        for (int k = 0; k < O; ++k) {
+            for (size_t e = 0; e < n; ++e) { ff[e] = (float)f[n * k + e]; x[e] = ff[e]; y1[e] = 0.0f; y2[e] = 0.0f; }
+            for (int it = 0; it < maxiter; ++it) {
+                const float tau = (float)tab[5 * it], sigma = (float)tab[5 * it + 1], omega = (float)tab[5 * it + 2];
+                const float inv1ptau = (float)tab[5 * it + 3], opw = (float)tab[5 * it + 4];
+                for (int j = 0; j < N; ++j)
+                    for (int i = 0; i < M; ++i) {
+                        size_t q = i + (size_t)M * j;
+                        float y1m = (i > 0) ? y1[q - 1] : 0.0f;
+                        float y2m = (j > 0) ? y2[q - M] : 0.0f;
+                        float div = (y1m - y1[q]) + (y2m - y2[q]);
+                        float t = div - ff[q];
+                        float xo = x[q];
+                        float xn = fmaf(-tau, t, xo) * inv1ptau;
+                        xb[q] = fmaf(-omega, xo, opw * xn);
+                        x[q] = xn;
+                    }
+                for (int j = 0; j < N; ++j)
+                    for (int i = 0; i < M; ++i) {
+                        size_t q = i + (size_t)M * j;
+                        float d1 = (i < M - 1) ? xb[q + 1] - xb[q] : 0.0f;
+                        float d2 = (j < N - 1) ? xb[q + M] - xb[q] : 0.0f;
+                        float a = alpha_at_f(al, am, an, M, N, i, j);
+                        float y1n = fmaf(sigma, d1, y1[q]);
+                        float y2n = fmaf(sigma, d2, y2[q]);
+                        if (rho != 0.0f) {
+                            float den = 1.0f + sigma * rho / a;
+                            y1n = y1n / den;
+                            y2n = y2n / den;
+                        }
+                        float n2 = fmaf(y2n, y2n, y1n * y1n);
+                        if (n2 > a * a) {
+                            float v = a * rsqrt_nr_f(n2);
+                            y1n = y1n * v;
+                            y2n = y2n * v;
+                        }
+                        y1[q] = y1n;
+                        y2[q] = y2n;
+                    }
+            }
+            for (size_t e = 0; e < n; ++e) x_out[n * k + e] = (double)x[e];
+        }
+    }
+    free(tab); free(ff); free(x); free(y1); free(y2); free(xb); free(al);
+    return rc;
+}
+
 /* The same recurrence with the work of ONE iteration spread over images x column blocks ("OpenMP over
  * images then rows"): all threads sweep the primal pass, barrier, the dual pass,
  * barrier.  Same per-pixel operations as pdhg_image, hence the same bits.  Used by bench.py's cpu_baseline

@@ -32,6 +32,9 @@ def lib():
         L.bplo_pdhg.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
         L.bplo_pdhg.restype = C.c_int
+        L.bplo_pdhg_f32.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_int, _dp]
+        L.bplo_pdhg_f32.restype = C.c_int
         L.bplo_pdhg_rows.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
                                      C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_int, C.c_int]
         L.bplo_pdhg_rows.restype = C.c_int
@@ -113,6 +116,20 @@ def pdhg(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True,
     if return_dual:
         return x, y1.reshape(f.shape), y2.reshape(f.shape)
     return x
+
+
+def pdhg_f32(f, alpha, maxiter=5000, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True):
+    """"spec v2f": the recurrence in single precision (bplo_pdhg_f32), the checker of the library's opt-in
+    dtype = 32 mode.  Returns the primal widened to float64."""
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3)
+    rc = lib().bplo_pdhg_f32(M, N, O, _p(f3), _p(a), am, an, rho, tau0, sigma0, int(accel), maxiter, _p(x))
+    if rc:
+        raise RuntimeError("bplo_pdhg_f32 rc=%d" % rc)
+    return x.reshape(f.shape)
 
 
 VARIANT_FLAGS = {"x0_zero": 1, "dual_first": 2, "ieee_sqrt_div": 4, "max_form": 8, "omega_of_new_tau": 16}

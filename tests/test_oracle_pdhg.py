@@ -63,3 +63,16 @@ def test_cost(oracle):
     tot, per = oracle.cost(f, ub, per_image=True)
     assert np.isclose(tot, T.l2_cost(f, ub), rtol=1e-14)
     assert np.isclose(per.sum(), tot, rtol=1e-15)
+
+
+def test_f32_twin_tracks_the_f64_recurrence(oracle):
+    """"spec v2f" (the checker of the library's opt-in dtype = 32 mode) stays within single-precision distance of
+    the Float64 recurrence; alpha = 0 leaves f to rounding."""
+    rng = np.random.default_rng(3)
+    f = rng.random((2, 24, 20))
+    a64 = oracle.pdhg(f, 0.1, maxiter=400)
+    a32 = oracle.pdhg_f32(f, 0.1, maxiter=400)
+    assert 0 < np.abs(a64 - a32).max() < 1e-5
+    assert np.abs(oracle.pdhg_f32(f, 0.0, maxiter=20) - f).max() < 1e-6    # (x + tau f) / (1 + tau) in float
+    amap = 0.05 + 0.1 * rng.random((24, 20))
+    assert np.abs(oracle.pdhg(f, amap, maxiter=200) - oracle.pdhg_f32(f, amap, maxiter=200)).max() < 1e-5
