@@ -140,9 +140,7 @@ __device__ __forceinline__ void bcr_winv_tile(double* __restrict__ S, int ld, in
 
 // Block column p (16 columns, rows 16p .. MP-1, already updated with the columns to its left) of the matrix in S,
 // factored by one wave in registers: lane l holds row 16p + l (and row 16p + 64 + l when TWO: more than 64 rows).
-// Per pivot: rsqrt chain on the broadcast pivot, scaling, rank-1 update of the columns to the right with the pivot
-// column's entries L(16p + q, c) broadcast by readlane.  Writes L back (zeros above the diagonal of the diagonal
-// tile) and 1 / L(r, r) to dinv.
+// Writes L back (zeros above the diagonal of the diagonal tile) and 1 / L(r, r) to dinv.
 template <bool TWO>
 __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld, int MP, int p, int lane,
                                                  double* __restrict__ dinv) {
@@ -157,13 +155,14 @@ __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld,
     }
     // Left-looking inside the block column, written in the order the dependent chain wants: column q receives its
     // last term (from column q-1), its pivot goes into the rsqrt chain, and while that runs column q+1 is brought up
-    // to date with the columns 0..q-1.  Every broadcast entry L(16p + q, c) = readlane(column c, q) is used at once.
+    // to date with the columns 0..q-1.  Every multiplier L(16p + q, c) = readlane(column c, q) is used at once.
+    // (Reading the off-chain multipliers back from LDS instead -- each finished column stored at once -- was slower:
+    // 2.5 us against 2.0 us per block column; the wait for the store sits on the chain.)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         if (q > 0) {
             const double l = readlane_f64(m0[q - 1], q);
             m0[q] = __builtin_fma(-m0[q - 1], l, m0[q]);
-            if (TWO) m1[q] = __builtin_fma(-m1[q - 1], l, m1[q]);
         }
         const double piv = readlane_f64(m0[q], q);
         if (!(piv > 0.0)) bad = true;
@@ -173,16 +172,32 @@ __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld,
             for (int c = 0; c < q; ++c) {
                 const double l = readlane_f64(m0[c], q + 1);
                 m0[q + 1] = __builtin_fma(-m0[c], l, m0[q + 1]);
-                if (TWO) m1[q + 1] = __builtin_fma(-m1[c], l, m1[q + 1]);
             }
         }
         m0[q] *= dv[q];   // the scaled column (its diagonal entry, the sqrt, is merged in at the write-back)
-        if (TWO) m1[q] *= dv[q];
     }
+    // the diagonal tile and the rows below it (first 64 rows of the block column) back to LDS
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < 16; ++c)
         if (v0) S[r0 + ld * (16 * p + c)] = (lane < 16 && c >= lane) ? ((c == lane) ? dd[c] : 0.0) : m0[c];
-        if (TWO && v1) S[r1 + ld * (16 * p + c)] = m1[c];
+    // The rows 64.. do not feed the pivots: they follow in a pass of their own with the finished tile, its entries
+    // L(16p + q, c) read from LDS as broadcast loads (right-looking, 15 - c independent updates per column).
+    // Interleaved with the chain above -- or fed by readlane here -- this pass cost as much as the chain itself
+    // (an SGPR broadcast costs ~13 cycles per instruction around it): 4.1 -> 3.1 us per block column.
+    if (TWO) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double* Lt = S + 16 * p + ld * (16 * p);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            m1[c] *= dv[c];
+#pragma unroll
+            for (int q = c + 1; q < 16; ++q) m1[q] = __builtin_fma(-m1[c], Lt[q + ld * c], m1[q]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (v1) S[r1 + ld * (16 * p + c)] = m1[c];
     }
     if (lane < 16) {
         double mine = dv[0];
