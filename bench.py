@@ -326,6 +326,8 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf)).get("workloads", {}).get(wl_key)
+                if args.f32:
+                    tj = None   # the committed counters are those of the Float64 kernel
                 if tj and tj.get("tile_iters") == st["tile_iters"] and tj.get("tiles") == st["tiles"]:
                     traffic = tj.get("hbm_bytes_per_launch")
                     valu_instr = tj.get("valu_wave_instructions_per_launch")

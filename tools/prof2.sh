@@ -3,14 +3,14 @@
 # Every rocprofv3 --pmc pass holds counters of ONE budget class that fits the hardware (MI355X_MICROARCH.md,
 # "rocprofv3 PMC slots": SQ 8 per pass; TCC 4, FETCH_SIZE costs 3 and WRITE_SIZE 2 -> separate passes), the
 # program comes directly after `--`, and no trace domain is combined with --pmc.
-# usage: tools/prof2.sh [part ...]   parts: bench cfg5 eval128 evalcfg5 sumregs   (default: all)
+# usage: tools/prof2.sh [part ...]   parts: bench cfg5 eval128 evalcfg5 sumregs f32   (default: all)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof2
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
-PARTS=${@:-bench cfg5 eval128 evalcfg5 sumregs}
+PARTS=${@:-bench cfg5 eval128 evalcfg5 sumregs f32}
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
 SQ2="SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
 kt()  { local tag=$1; shift; echo "== kernel trace $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
@@ -49,6 +49,13 @@ evalcfg5)
   # the banded factorisation of this run (40k dispatches; also with BPLTV_HB_SINGLE_STREAM=1), and a 2 x 512^2
   # case does not finish in 5 minutes under counters.  The kernel trace + timeline above are the evidence for the
   # HBM band kernels; tools/lu_unit.hip checks them numerically.
+  ;;
+f32)
+  # the opt-in single-precision mode (never the headline): both shapes, no counters
+  python3 bench.py --f32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_f32.log 2>&1 || { tail -20 $OUT/bench_f32.log; exit 1; }
+  tail -1 $OUT/bench_f32.log | cut -c1-300
+  python3 bench.py --f32 --images 8 --size 1024 --alpha-map --iters 400 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg5_f32.log 2>&1 || { tail -20 $OUT/bench_cfg5_f32.log; exit 1; }
+  tail -1 $OUT/bench_cfg5_f32.log | cut -c1-300
   ;;
 sumregs)
   python3 tools/gpu_sumregs_time.py > $OUT/sumregs_time.log 2>&1 || { tail -20 $OUT/sumregs_time.log; exit 1; }

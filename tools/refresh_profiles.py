@@ -119,7 +119,8 @@ def publish(tag):
         p = newest(os.path.join(sub, "**", "pmc_summary.csv"))
         if p:
             shutil.copy(p, os.path.join(PRO, "%s_%s_summary.csv" % (tag, name))); copied.append(name)
-    for log, name in (("bench.log", "bench_line"), ("bench_cfg5.log", "bench_line_cfg5")):
+    for log, name in (("bench.log", "bench_line"), ("bench_cfg5.log", "bench_line_cfg5"), ("bench_f32.log", "bench_line_f32"),
+                      ("bench_cfg5_f32.log", "bench_line_cfg5_f32")):
         p = os.path.join(SRC, log)
         if os.path.exists(p):
             lines = [l for l in open(p) if l.startswith("{")]
