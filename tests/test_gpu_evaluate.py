@@ -176,7 +176,8 @@ def test_breakdown_retry_is_visible_and_arguments_are_validated(gpu_solver_cls):
 
 
 @pytest.mark.parametrize("shape,alpha", [((2, 40, 200), 0.1), ((1, 70, 150), np.array([[0.06, 0.15], [0.1, 0.2]])),
-                                         ((1, 36, 160), "map")], ids=["scalar200", "patch150", "map160"])
+                                         ((1, 36, 160), "map"), ((1, 45, 139), 0.08), ((3, 20, 257), "map")],
+                         ids=["scalar200", "patch150", "map160", "scalar139_odd_band", "map257_three_images"])
 def test_wide_images_use_the_hbm_band_path(gpu_solver_cls, oracle, shape, alpha):
     """M > 138 does not fit the LDS window: the band is factored in place in HBM (one launch pair
     per panel).  Same reduced system, same tolerance against the oracle."""
