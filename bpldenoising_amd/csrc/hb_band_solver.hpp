@@ -264,7 +264,6 @@ struct HbBandSolver {
         return 0;
     }
 
-    // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim)
     // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim): one launch per block of
     // 128 columns.  (Groups of four blocks per launch -- every workgroup solving the 512 x 512 triangle of the group
     // redundantly, 14 operand blocks streamed through its registers, then applying it to its own rows -- were built and
