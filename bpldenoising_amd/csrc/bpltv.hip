@@ -916,7 +916,9 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     // sweep already reaches the level the block-cyclic-reduction path needs two for (tools/gpu_refine_hbm.py,
     // 1024^2: pixel map 3.6e-9 / patch 6e-11 / regularised 1e-16 from the converged value after ONE sweep, scalar
     // 1.4e-9 after two), and every sweep costs two full substitutions of the 8.6 GB factor.
-    const int nref_default = (method == ADJ_BAND_HBM) ? ((patch || reg) ? 1 : 2) : ((patch || reg) ? 2 : 3);
+    // The regularised systems (gamma = 1e8 instead of 1/eps) need none: 4e-10 / 1e-9 / 5e-11 from the converged
+    // value without a sweep, scaled residual <= 4e-12.
+    const int nref_default = (method == ADJ_BAND_HBM) ? (reg ? 0 : (patch ? 1 : 2)) : ((patch || reg) ? 2 : 3);
     const int nref = p.refine < 0 ? nref_default : p.refine;
     AdjCoef C;
     C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;

@@ -69,7 +69,8 @@ typedef struct bpltv_params {
     int use_graph;       /* 1 (default): replay the launch sequence from a hipGraph               */
     double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
     int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3 for the
-                            scalar gradient, 2 for patch / pixel-map parameters and gradient_reg)  */
+                            scalar gradient, 2 for patch / pixel-map parameters and gradient_reg; on the
+                            HBM band path of wide images 2 / 1 / 0)                               */
     int deterministic;   /* multi-GPU handles, scalar / patch parameters: 1 = all-gather the per-image rows
                             [cost_k, grad_k...] and add them in global image order, so that cost and grad are
                             bitwise the same for every number of GPUs (and equal to a single handle's);
