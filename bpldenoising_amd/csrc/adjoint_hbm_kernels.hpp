@@ -14,7 +14,8 @@
 //                      and P = L21 copied into the band
 // and per panel one launch of hb2_fwd_kernel / hb2_bwd_kernel per substitution.  (A first version with
 // 32-column panels, a register Cholesky, scalar updates and 64-column substitutions cost 3.5 s per
-// 8 x 1024^2 gradient; these kernels 1.25-1.4 s)
+// 8 x 1024^2 gradient; these kernels 1.25 s launched one after the other, 0.54 s as the twisted three-stream
+// pipeline of hb_band_solver.hpp)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "adjoint_kernels.hpp"
