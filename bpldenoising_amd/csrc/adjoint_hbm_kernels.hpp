@@ -503,6 +503,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
     double va[8], vb[8];
+    if (part == 2) BCR_PROBE(32);
     hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, 0, tid, va);
     hb2_fetch_dense(Pj, bwp, bwp, HB2_NB, 64 * tb, 0, tid, vb);
     constexpr int nchunk = HB2_NB / BG_KC;
@@ -511,29 +512,49 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
         bg_stage<true>(As, tid, va);
         bg_stage<true>(Bs, tid, vb);
         __syncthreads();
+        if (part == 2) BCR_PROBE(33 + 2 * ch);
         if (ch + 1 < nchunk) {
             hb2_fetch_dense(Pi, bwp, bwp, HB2_NB, 64 * ta, (ch + 1) * BG_KC, tid, va);
             hb2_fetch_dense(Pj, bwp, bwp, HB2_NB, 64 * tb, (ch + 1) * BG_KC, tid, vb);
         }
         hb2_mma_chunk(As, Bs, acc);
+        if (part == 2) BCR_PROBE(34 + 2 * ch);
     }
     const int l = tid & 63, hq = tid >> 6;
     double old[16];   // requested together, before the accumulators go through LDS
+    // Interior tiles (strictly below the diagonal, inside the band and the matrix: nearly all of them) need none of
+    // the six tests per entry: entry (l, hq + 4 i) of the tile sits at a constant stride of 4 (W - 1) doubles.
+    const bool interior = ta > tb && base + 64 * ta + 63 < n && 64 * (ta - tb) + 63 <= bw && 64 * ta + 63 < bw;
+    double* t0 = Bi + (size_t)(base + 64 * tb + hq) * W + (64 * (ta - tb) + l - hq);
+    const size_t tstep = (size_t)4 * (W - 1);
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int o = hq + 4 * i;
-        const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
-        const bool in = R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw;
-        old[i] = in ? Bi[(size_t)Cc * W + (R - Cc)] : 0.0;
+        for (int i = 0; i < 16; ++i) old[i] = t0[i * tstep];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = hq + 4 * i;
+            const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
+            const bool in = R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw;
+            old[i] = in ? Bi[(size_t)Cc * W + (R - Cc)] : 0.0;
+        }
     }
+    if (part == 2) BCR_PROBE(41);
     bg_to_lds(acc, lds);
+    if (part == 2) BCR_PROBE(42);
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int o = hq + 4 * i;
-        const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
-        if (R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw)
-            Bi[(size_t)Cc * W + (R - Cc)] = old[i] - lds[o * BG_LD + l];
+        for (int i = 0; i < 16; ++i) t0[i * tstep] = old[i] - lds[(hq + 4 * i) * BG_LD + l];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = hq + 4 * i;
+            const int R = base + 64 * ta + l, Cc = base + 64 * tb + o;
+            if (R < n && Cc < n && R >= Cc && R - Cc <= bw && 64 * ta + l < bw && 64 * tb + o < bw)
+                Bi[(size_t)Cc * W + (R - Cc)] = old[i] - lds[o * BG_LD + l];
+        }
     }
+    if (part == 2) BCR_PROBE(43);
 }
 
 // Substitutions with L in the band array, one launch per 128-column block (a single workgroup streaming

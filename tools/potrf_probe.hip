@@ -45,6 +45,11 @@ int main(int argc, char** argv) {
         prev = h[9 + 2 * p];
     }
     printf("  tail: %.2f\n", (h[5] - prev) * 0.01);
+    printf("last bulk update launch, workgroup 0 (us): operands requested -> chunk 0 staged %.2f", us(32, 33));
+    for (int ch = 0; ch < 4; ++ch) printf(" | mfma %d %.2f", ch, us(33 + 2 * ch, 34 + 2 * ch));
+    for (int ch = 1; ch < 4; ++ch) printf(" | stage %d %.2f", ch, us(32 + 2 * ch, 33 + 2 * ch));
+    printf(" | old tile requested %.2f | acc to LDS (waits for the tile) %.2f | stores %.2f | total %.2f\n", us(40, 41), us(41, 42),
+           us(42, 43), us(32, 43));
     int f = 0; CK(hipMemcpy(&f, d_fail, sizeof(int), hipMemcpyDeviceToHost));
     printf("fail flag %d\n", f);
     return 0;
