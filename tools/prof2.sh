@@ -44,7 +44,9 @@ evalcfg5)
   python3 tools/eval_cfg5.py 8 3 400 > $OUT/eval_cfg5.log 2>&1 || { tail -20 $OUT/eval_cfg5.log; exit 1; }
   cat $OUT/eval_cfg5.log
   python3 tools/eval_cfg5.py 1 2 400 >> $OUT/eval_cfg5.log 2>&1 || { tail -20 $OUT/eval_cfg5.log; exit 1; }
-  kt kt_evalcfg5 python3 tools/eval_cfg5.py 8 1 400
+  # the trace is taken with event-based stream dependencies: rocprofv3 stalls every stream memory operation of the
+  # default (hipStreamWaitValue32) and would show a timeline the unprofiled run does not have
+  BPLTV_HB_SYNC=event kt kt_evalcfg5 python3 tools/eval_cfg5.py 8 1 400
   # No --pmc pass here: rocprofv3 (ROCm 7.2) segfaults inside its own counter-collection path on the first launch of
   # the banded factorisation of this run (40k dispatches; also with BPLTV_HB_SINGLE_STREAM=1), and a 2 x 512^2
   # case does not finish in 5 minutes under counters.  The kernel trace + timeline above are the evidence for the
