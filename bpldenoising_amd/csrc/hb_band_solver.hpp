@@ -276,6 +276,15 @@ struct HbBandSolver {
     int factor(const BandDiags& D, int* d_fail_out) {
         const size_t W = (size_t)bw + 1;
         HBCHK(hipMemsetAsync(fail, 0, (size_t)O * 3 * sizeof(int), stream));
+        if (value_sync && *std::max_element(seq, seq + 4) > 0xF0000000u) {   // counters near wrap-around: start over
+            HBCHK(hipStreamSynchronize(stream));
+            HBCHK(hipStreamSynchronize(stream2));
+            HBCHK(hipStreamSynchronize(stream3));
+            for (int q = 0; q < 4; ++q) {
+                HBCHK(hipMemset(sig[q], 0, 8));
+                seq[q] = 0;
+            }
+        }
         if (prefilled) {   // the band is zero: write only the diagonals
             HBCHK(hipStreamWaitEvent(stream, ev[2], 0));
             const unsigned gb = (unsigned)std::min<size_t>(((size_t)np + 255) / 256, 65536);
