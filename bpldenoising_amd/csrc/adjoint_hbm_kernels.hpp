@@ -476,7 +476,12 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
     if (cpP) {
         const int cbase = cpk0 + HB2_NB;
         const double* Pc = cpP + (size_t)img * bwp * HB2_NB;
-        for (int tc = bx; tc < nt; tc += gx) {
+        // a part-1 launch with more workgroups than tiles: the extra ones do the copies and the tile workgroups start
+        // their products at once (the launch is as long as its slowest workgroup, and it sits on the stream that
+        // bounds the pipeline)
+        const int ntile = (part == 1) ? hb2_update_tiles(nt, 1) : gx;
+        const int c0 = gx > ntile ? bx - ntile : bx, cs = gx > ntile ? gx - ntile : gx;
+        for (int tc = c0; tc >= 0 && tc < nt; tc += cs) {
             if (cbase + 64 * tc >= n) continue;
             for (int e0 = tid; e0 < 64 * HB2_NB; e0 += 16 * BG_T) {
                 double v[16];

@@ -236,8 +236,9 @@ struct HbBandSolver {
                 hipLaunchKernelGGL(hb2_update_kernel, dim3(g0 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 0,
                                    nprob, nul, nul, 0);
             if (ms && haveU2) await(sA, tU2);     // U2(k-1)
-            hipLaunchKernelGGL(hb2_update_kernel, dim3(g1 * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp, bwp, 1, nprob,
-                               nul, Plast, k0last);
+            // (+ nt workgroups per problem that only copy, when there is a panel to copy)
+            hipLaunchKernelGGL(hb2_update_kernel, dim3((g1 + (Plast ? nt : 0)) * nprob), dim3(BG_T), 0, sA, B, bw, nrow, k0, (const double*)Pp,
+                               bwp, 1, nprob, nul, Plast, k0last);
             Plast = Pp; k0last = k0;
             if (ms) tU1[k & 1] = post(SIG_U1, sA, ev1[k & 1]);
             if (g2 > 0) {
