@@ -36,8 +36,16 @@ typedef double bcr_d4 __attribute__((ext_vector_type(4)));
 #ifdef BCR_PROBE_ON   // tools/potrf_probe.hip only: time stamps (s_memrealtime, 100 MHz) of workgroup 0's phases
 __device__ long long bcr_probe_buf[64];
 #define BCR_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) bcr_probe_buf[i] = (long long)wall_clock64(); } while (0)
+// span of a launch over all its workgroups: [kind][panel & 63] = {earliest start, latest end}
+__device__ unsigned long long bcr_span[4][64][2];
+#define BCR_SPAN_BEGIN(kind, panel) do { if (threadIdx.x == 0) atomicMin(&bcr_span[kind][(panel) & 63][0], (unsigned long long)wall_clock64()); } while (0)
+#define BCR_SPAN_END(kind, panel) do { if (threadIdx.x == 0) atomicMax(&bcr_span[kind][(panel) & 63][1], (unsigned long long)wall_clock64()); } while (0)
+#define BCR_SPAN_RESET(kind, panel) do { if (threadIdx.x == 0 && blockIdx.x == 0) { bcr_span[kind][((panel) + 32) & 63][0] = ~0ull; bcr_span[kind][((panel) + 32) & 63][1] = 0ull; } } while (0)
 #else
 #define BCR_PROBE(i) do { } while (0)
+#define BCR_SPAN_BEGIN(kind, panel) do { } while (0)
+#define BCR_SPAN_END(kind, panel) do { } while (0)
+#define BCR_SPAN_RESET(kind, panel) do { } while (0)
 #endif
 
 #ifdef BCR_DBG   // timing experiments of tools/bcr_unit.hip only (results are wrong when set)

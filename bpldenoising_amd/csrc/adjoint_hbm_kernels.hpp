@@ -173,6 +173,7 @@ __device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img
         if (c >= r) LiT[e] = S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))];
     }
     BCR_PROBE(6);
+    BCR_SPAN_END(0, k0 / MP);
 }
 
 // The dependent chain of the banded Cholesky in ONE launch per panel (one workgroup per problem): the diagonal
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
     constexpr int MP = HB2_NB, ld = MP + 1;
     const int W = bw + 1;
     const int img = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    BCR_SPAN_RESET(0, k0 / MP);
+    BCR_SPAN_BEGIN(0, k0 / MP);
     const double* Bi = band + (size_t)img * n * W;
     const double* Bd = Bi + (size_t)k0 * W;                   // A(k0+r, k0+c) = Bd[r + (W-1) c], r >= c
     if (k0 == 0) {
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
     const int bxt = (int)(blockIdx.x / (unsigned)nprob);
     const int rt = bxt >> 1, c0 = (bxt & 1) * 64;
     const int R0 = k0 + HB2_NB + 64 * rt;
+    BCR_SPAN_RESET(1, k0 / HB2_NB);
+    BCR_SPAN_BEGIN(1, k0 / HB2_NB);
     if (R0 >= n) return;
     const double* Bi = band + (size_t)img * n * W;
     const double* Li = Linv + ((size_t)img * npanel + k0 / HB2_NB) * HB2_NB * HB2_NB;
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(4))) void 
         const int o = hq + 4 * i;
         Pi[(64 * rt + l) + (size_t)bwp * (c0 + o)] = lds[o * BG_LD + l];
     }
+    BCR_SPAN_END(1, k0 / HB2_NB);
 }
 
 // Trailing update A(R, C) -= sum_k P(R, k) P(C, k) on the lower 64x64 tiles (ta >= tb) of the bw x bw block
@@ -447,6 +453,10 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
     const double* Pj = PB ? PB + (size_t)img * bwp * HB2_NB : Pi;
     const int nt = (bw + 63) / 64;
     const int bx = (int)(blockIdx.x / (unsigned)nprob), gx = (int)(gridDim.x / (unsigned)nprob);
+    if (part == 1 || part == 2) {
+        BCR_SPAN_RESET(1 + part, k0 / HB2_NB);
+        BCR_SPAN_BEGIN(1 + part, k0 / HB2_NB);
+    }
     int ta = -1, tb = -1;   // tile of this workgroup (none: copies only)
     if (part == 0) {
         int t = bx; ta = 0;
@@ -560,6 +570,7 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
         }
     }
     if (part == 2) BCR_PROBE(43);
+    if (part == 1 || part == 2) BCR_SPAN_END(1 + part, k0 / HB2_NB);
 }
 
 // Substitutions with L in the band array, one launch per 128-column block (a single workgroup streaming

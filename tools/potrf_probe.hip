@@ -50,6 +50,24 @@ int main(int argc, char** argv) {
     for (int ch = 1; ch < 4; ++ch) printf(" | stage %d %.2f", ch, us(32 + 2 * ch, 33 + 2 * ch));
     printf(" | old tile requested %.2f | acc to LDS (waits for the tile) %.2f | stores %.2f | total %.2f\n", us(40, 41), us(41, 42),
            us(42, 43), us(32, 43));
+    {   // launch spans of the last panels (all workgroups): C = chain, T = trsm, U1 / U2 = update parts
+        static unsigned long long sp[4][64][2];
+        CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(bcr_span), sizeof(sp)));
+        const int npan = (n + 127) / 128;
+        unsigned long long t0 = ~0ull;
+        for (int k = npan - 30; k < npan - 20; ++k) if (k >= 0 && sp[0][k & 63][0] < t0) t0 = sp[0][k & 63][0];
+        printf("launch spans, panels %d..%d (us from the first chain kernel): begin-end of C | T | U1 | U2\n", npan - 30, npan - 21);
+        for (int k = npan - 30; k < npan - 20; ++k) {
+            if (k < 0) continue;
+            printf("  panel %4d:", k);
+            for (int kind = 0; kind < 4; ++kind) {
+                const unsigned long long b = sp[kind][k & 63][0], e = sp[kind][k & 63][1];
+                if (b == ~0ull || e == 0) printf("        -        |");
+                else printf(" %7.1f-%7.1f |", (double)(long long)(b - t0) * 0.01, (double)(long long)(e - t0) * 0.01);
+            }
+            printf("\n");
+        }
+    }
     int f = 0; CK(hipMemcpy(&f, d_fail, sizeof(int), hipMemcpyDeviceToHost));
     printf("fail flag %d\n", f);
     return 0;
