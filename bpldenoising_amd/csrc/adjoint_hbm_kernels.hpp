@@ -581,29 +581,44 @@ __global__ __launch_bounds__(BG_T) __attribute__((amdgpu_waves_per_eu(3))) void 
 // 128 rows of the band (thread (row, part): 16 consecutive columns each, partial sums meet in LDS).
 // Forward (L y = b):   in/out `x` = running right-hand side, solution rows -> `y`.
 // Backward (L^T x = y): in/out `y` = running right-hand side, solution rows -> `x` (and += acc).
-// grid (1 + ceil(bw/128), O), block BS_T.
+// RW = rows (forward) / earlier equations (backward) per tile workgroup: 128 = one workgroup per 128 x 128 tile; 32 =
+// four workgroups per tile, each streaming the 64 KB inverse block and a quarter of the tile -- a launch is as long as
+// one CU needs for its workgroup's bytes, and the inverse block is the part every workgroup has to read.
+// grid (1 + ceil(bw / RW), O), block BS_T.
+__host__ __device__ inline unsigned hb2_subst_grid(int bw, int RW) { return 1u + (unsigned)((bw + RW - 1) / RW); }
+
+template <int RW>
 __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict__ band, const double* __restrict__ Linv,
                                                        int bw, int n, int k0, int npanel, double* __restrict__ x,
                                                        double* __restrict__ y, int unit_diag = 0) {
+    constexpr int NPART = BS_T / RW, CP = HB2_NB / NPART;   // parts of a row, columns per part
     __shared__ double v[HB2_NB], yb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
+    static_assert(NPART * RW <= BS_W * BS_MP, "partial sums fit the reduction buffer");
     const int W = bw + 1;
     const int img = blockIdx.y, tid = threadIdx.x;
     const double* Bi = band + (size_t)img * n * W;
     double* xv = x + (size_t)img * n;
+#ifdef BCR_PROBE_ON
+#define HB2_FP(i) do { if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 0) bcr_probe_buf[i] = (long long)wall_clock64(); } while (0)
+#else
+#define HB2_FP(i) do { } while (0)
+#endif
+    HB2_FP(50);
     if (tid < HB2_NB) v[tid] = (k0 + tid < n) ? xv[k0 + tid] : 0.0;
-    // this workgroup's 128 x 128 tile of L is requested BEFORE the diagonal-block product: its addresses do not
-    // depend on the solution, so its memory latency overlaps with that of the 128 KB inverse block
-    const int rr = tid & 127, part = tid >> 7;
-    const int R = k0 + HB2_NB + ((int)blockIdx.x - 1) * HB2_NB + rr;
+    // this workgroup's rows of L are requested BEFORE the diagonal-block product: their addresses do not
+    // depend on the solution, so their memory latency overlaps with that of the 128 KB inverse block
+    const int rr = tid % RW, part = tid / RW;
+    const int R = k0 + HB2_NB + ((int)blockIdx.x - 1) * RW + rr;
     const bool upd = blockIdx.x > 0 && R < n && R <= k0 + HB2_NB - 1 + bw;
-    double lt[16];
+    double lt[CP];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = 16 * part + i, d0 = R - (k0 + c);
+    for (int i = 0; i < CP; ++i) {
+        const int c = CP * part + i, d0 = R - (k0 + c);
         lt[i] = (upd && d0 <= bw) ? Bi[(size_t)(k0 + c) * W + d0] : 0.0;
     }
     __syncthreads();
+    HB2_FP(51);
     double val;
     if (unit_diag) {   // LU path: the diagonal block of L is the identity
         val = (tid < HB2_NB) ? v[tid] : 0.0;
@@ -616,37 +631,42 @@ __global__ __launch_bounds__(BS_T) void hb2_fwd_kernel(const double* __restrict_
         if (tid < HB2_NB && k0 + tid < n) y[(size_t)img * n + k0 + tid] = val;
         return;
     }
+    HB2_FP(52);
     if (tid < HB2_NB) yb[tid] = val;
     __syncthreads();
     double s = 0.0;
     if (upd) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const int c = 16 * part + i;
+        for (int i = 0; i < CP; i += 2) {
+            const int c = CP * part + i;
             a0 = __builtin_fma(lt[i], yb[c], a0);
             a1 = __builtin_fma(lt[i + 1], yb[c + 1], a1);
         }
         s = a0 + a1;
     }
-    red[part * BS_MP + rr] = s;
+    red[part * RW + rr] = s;
     __syncthreads();
-    if (tid < HB2_NB && upd) {
+    HB2_FP(53);
+    if (tid < RW && upd) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q * BS_MP + tid];
+        for (int q = 0; q < NPART; ++q) t += red[q * RW + tid];
         xv[R] -= t;
     }
+    HB2_FP(54);
 }
 
 // apply_only (twisted solve): block k0 lies in the trailing window of a partially factored problem; its
 // solution is already in `x` (the middle block's), only the earlier equations are updated.
 // mvmode: 2 = `LinvT` is upper triangular (Cholesky); 0 = a full matrix (LU path: the inverse of the diagonal block
 // of U, with `band` = the upper band stored by rows).
+template <int RW>
 __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict__ band, const double* __restrict__ LinvT,
                                                        int bw, int n, int k0, int npanel, double* __restrict__ y,
                                                        double* __restrict__ x, double* __restrict__ acc, int apply_only,
                                                        int mvmode = 2) {
+    constexpr int NPART = BS_T / RW, CP = HB2_NB / NPART;   // parts of a column, rows per part
     __shared__ double v[HB2_NB], xb[HB2_NB];
     __shared__ __attribute__((aligned(16))) double red[BS_W * BS_MP];
     const int W = bw + 1;
@@ -655,23 +675,23 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
     double* yv = y + (size_t)img * n;
     // this workgroup's rows of L^T (earlier equation k: y_k -= sum_c L[k0+c][k] x_{k0+c}, L[k0+c][k] = band[k*W + (k0+c-k)])
     // are requested BEFORE the diagonal-block product: their addresses do not depend on the solution
-    const int rr = tid & 127, part = tid >> 7;
-    const int k = k0 - 1 - (((int)blockIdx.x - 1) * HB2_NB + rr);
+    const int rr = tid % RW, part = tid / RW;
+    const int k = k0 - 1 - (((int)blockIdx.x - 1) * RW + rr);
     const bool upd = blockIdx.x > 0 && k >= 0 && k0 - k <= bw;
-    const int cb = 16 * part;
-    double lt[16];
+    const int cb = CP * part;
+    double lt[CP];
     {
         const double* col = Bi + (size_t)(upd ? k : 0) * W + (upd ? k0 - k : 0);
-        if (upd && (bw & 1) == 0 && (((size_t)img * n) & 1) == 0 && k0 - k + cb + 15 <= bw && k0 + cb + 15 < n) {
-            // the thread's 16 entries are one 128-byte line: eight 16-byte loads (k(W-1) + k0 is even for even bw)
+        if (upd && (bw & 1) == 0 && (((size_t)img * n) & 1) == 0 && k0 - k + cb + CP - 1 <= bw && k0 + cb + CP - 1 < n) {
+            // the thread's entries are contiguous: 16-byte loads (k(W-1) + k0 is even for even bw)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < CP / 2; ++i) {
                 const double2 q = *reinterpret_cast<const double2*>(col + cb + 2 * i);
                 lt[2 * i] = q.x; lt[2 * i + 1] = q.y;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < CP; ++i) {
                 const int c = cb + i;
                 lt[i] = (upd && k0 - k + c <= bw && k0 + c < n) ? col[c] : 0.0;
             }
@@ -700,18 +720,18 @@ __global__ __launch_bounds__(BS_T) void hb2_bwd_kernel(const double* __restrict_
     if (upd) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
+        for (int i = 0; i < CP; i += 2) {
             a0 = __builtin_fma(lt[i], xb[cb + i], a0);
             a1 = __builtin_fma(lt[i + 1], xb[cb + i + 1], a1);
         }
         s = a0 + a1;
     }
-    red[part * BS_MP + rr] = s;
+    red[part * RW + rr] = s;
     __syncthreads();
-    if (tid < HB2_NB && upd) {
+    if (tid < RW && upd) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q * BS_MP + tid];
+        for (int q = 0; q < NPART; ++q) t += red[q * RW + tid];
         yv[k] -= t;
     }
 }

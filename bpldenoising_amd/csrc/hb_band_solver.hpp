@@ -56,6 +56,7 @@ struct HbBandSolver {
     bool value_sync = false, sync_err = false;
     unsigned* sig[4] = {nullptr, nullptr, nullptr, nullptr};   // counters in signal memory (value_sync)
     unsigned seq[4] = {0, 0, 0, 0};
+    int rw_force = 0;            // BPLTV_HB_RW = 32 | 128: rows per tile workgroup of the substitutions (0: by size)
     bool single_stream = false;  // profiling aid (BPLTV_HB_SINGLE_STREAM=1): rocprofv3 --pmc cannot follow two streams
     std::string err;
 
@@ -118,6 +119,9 @@ struct HbBandSolver {
         const size_t W = (size_t)bw + 1;
         const char* e1 = getenv("BPLTV_HB_SINGLE_STREAM");
         single_stream = e1 && e1[0] == '1';
+        const char* e6 = getenv("BPLTV_HB_RW");
+        rw_force = e6 ? atoi(e6) : 0;
+        if (rw_force != 32 && rw_force != 128) rw_force = 0;
         {   // cross-stream dependencies by stream memory operations where the device has them (BPLTV_HB_SYNC=event:
             // HIP events instead; rocprofv3 needs that -- it stalls every stream memory operation)
             const char* e4 = getenv("BPLTV_HB_SYNC");
@@ -311,25 +315,49 @@ struct HbBandSolver {
         return 0;
     }
 
+    // rows per tile workgroup of a substitution launch: the fewer, the fewer bytes a CU has to stream for its
+    // workgroup (every workgroup reads the 64 KB inverse block besides its share of the tile).
+    // Measured on 1024^2 images (adjoint per gradient, 32 against 128 rows): 1 image 0.395 / 0.434 s, 2 images
+    // 0.401 / 0.444 s, 4 images 0.455 / 0.460 s, 8 images 0.536 / 0.497 s (64 rows: 0.525 s) -- with 16 problems per
+    // launch the substitutions are bound by HBM bandwidth and the extra reads of the inverse block cost more than
+    // the shorter workgroups gain.
+    int subst_rw(int nprob) const {
+        if (rw_force) return rw_force;
+        return (long)hb2_subst_grid(bw, 32) * nprob <= 288 ? 32 : 128;
+    }
+    template <int RW>
+    void fwd_rw(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* x, double* y) {
+        const unsigned chunks = hb2_subst_grid(bw, RW);
+        for (int k0 = 0; k0 < nelim; k0 += HB2_NB)
+            hipLaunchKernelGGL(hb2_fwd_kernel<RW>, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.Linv, bw, nrow, k0, hb.npanel, x, y, 0);
+    }
+    template <int RW>
+    void bwd_rw(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* y, double* x, double* acc) {
+        const unsigned chunks = hb2_subst_grid(bw, RW);
+        // rows of the trailing window (partial factorisation): their solution is given, push it to the earlier rows
+        for (int k0 = ((nrow - 1) / HB2_NB) * HB2_NB; k0 >= nelim; k0 -= HB2_NB)
+            hipLaunchKernelGGL(hb2_bwd_kernel<RW>, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x,
+                               (double*)nullptr, 1, 2);
+        for (int k0 = ((nelim - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
+            hipLaunchKernelGGL(hb2_bwd_kernel<RW>, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x, acc,
+                               0, 2);
+    }
     // forward / backward sweeps of `nprob` problems over the blocks of columns [0, nelim): one launch per block of
     // 128 columns.  (Groups of four blocks per launch -- every workgroup solving the 512 x 512 triangle of the group
     // redundantly, 14 operand blocks streamed through its registers, then applying it to its own rows -- were built and
     // measured: 10 us (forward) and 20 us (backward) per block against 7-9 us here.  One CU streams about 50 GB/s,
-    // so what a block needs has to stay spread over 9 CUs, 256 KB each, as these launches do.)
+    // so what a block needs has to stay spread over many CUs, as these launches do.)
     void fwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* x, double* y) {
-        const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
-        for (int k0 = 0; k0 < nelim; k0 += HB2_NB)
-            hipLaunchKernelGGL(hb2_fwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.Linv, bw, nrow, k0, hb.npanel, x, y, 0);
+        switch (subst_rw(nprob)) {
+            case 32: fwd_rw<32>(B, hb, nprob, nrow, nelim, x, y); break;
+            default: fwd_rw<128>(B, hb, nprob, nrow, nelim, x, y);
+        }
     }
     void bwd(const double* B, const Bufs& hb, int nprob, int nrow, int nelim, double* y, double* x, double* acc) {
-        const unsigned chunks = 1 + (unsigned)((bw + HB2_NB - 1) / HB2_NB);
-        // rows of the trailing window (partial factorisation): their solution is given, push it to the earlier rows
-        for (int k0 = ((nrow - 1) / HB2_NB) * HB2_NB; k0 >= nelim; k0 -= HB2_NB)
-            hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x,
-                               (double*)nullptr, 1, 2);
-        for (int k0 = ((nelim - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
-            hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, nprob), dim3(BS_T), 0, stream, B, hb.LinvT, bw, nrow, k0, hb.npanel, y, x, acc,
-                               0, 2);
+        switch (subst_rw(nprob)) {
+            case 32: bwd_rw<32>(B, hb, nprob, nrow, nelim, y, x, acc); break;
+            default: bwd_rw<128>(B, hb, nprob, nrow, nelim, y, x, acc);
+        }
     }
 
     // v <- A^-1 v, accv += solution (accv may be null).  scratch: [O][n] doubles (not twisted: holds y).

@@ -225,7 +225,7 @@ struct HbLuSolver {
         for (int k0 = 0; k0 < n; k0 += HB2_NB)
             hipLaunchKernelGGL(hb_lu_fwd_kernel, dim3(chunks, O), dim3(1024), 0, stream, (const double*)P(k0), bw, n, k0, bwp, v, scratch);
         for (int k0 = ((n - 1) / HB2_NB) * HB2_NB; k0 >= 0; k0 -= HB2_NB)
-            hipLaunchKernelGGL(hb2_bwd_kernel, dim3(chunks, O), dim3(BS_T), 0, stream, bandU, Ainv(), bw, n, k0, npanel, scratch, v, accv,
+            hipLaunchKernelGGL(hb2_bwd_kernel<HB2_NB>, dim3(chunks, O), dim3(BS_T), 0, stream, bandU, Ainv(), bw, n, k0, npanel, scratch, v, accv,
                                0, 0);
     }
 #undef LUCHK

@@ -68,6 +68,20 @@ int main(int argc, char** argv) {
             printf("\n");
         }
     }
+    {   // one solve: phases of the last forward-substitution launch (workgroup 1 of problem 0)
+        double *d_v, *d_s;
+        CK(hipMalloc(&d_v, (size_t)O * n * 8)); CK(hipMalloc(&d_s, (size_t)O * n * 8));
+        CK(hipMemset(d_v, 0, (size_t)O * n * 8));
+        CK(hipEventRecord(e0, st));
+        ch.solve(d_v, nullptr, d_s);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(bcr_probe_buf), sizeof(h)));
+        printf("solve %.3f ms = %.2f us per block and direction; last forward launch, a tile workgroup (us): loads issued + v staged %.2f"
+               " | Linv product + reduce %.2f | tile product + reduce %.2f | update stored %.2f | total %.2f\n",
+               ms, 1e3 * ms / (2.0 * ((n + 127) / 128)), us(50, 51), us(51, 52), us(52, 53), us(53, 54), us(50, 54));
+    }
     int f = 0; CK(hipMemcpy(&f, d_fail, sizeof(int), hipMemcpyDeviceToHost));
     printf("fail flag %d\n", f);
     return 0;
