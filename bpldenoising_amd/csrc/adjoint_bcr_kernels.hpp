@@ -35,7 +35,8 @@ typedef double bcr_d4 __attribute__((ext_vector_type(4)));
 
 #ifdef BCR_PROBE_ON   // tools/potrf_probe.hip only: time stamps (s_memrealtime, 100 MHz) of workgroup 0's phases
 __device__ long long bcr_probe_buf[64];
-#define BCR_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) bcr_probe_buf[i] = (long long)wall_clock64(); } while (0)
+__device__ int bcr_probe_on = 1;   // tools set it per launch range (e.g. only the chain kernel of one mid-run panel)
+#define BCR_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && bcr_probe_on) bcr_probe_buf[i] = (long long)wall_clock64(); } while (0)
 // span of a launch over all its workgroups: [kind][panel & 63] = {earliest start, latest end}
 __device__ unsigned long long bcr_span[4][64][2];
 #define BCR_SPAN_BEGIN(kind, panel) do { if (threadIdx.x == 0) atomicMin(&bcr_span[kind][(panel) & 63][0], (unsigned long long)wall_clock64()); } while (0)

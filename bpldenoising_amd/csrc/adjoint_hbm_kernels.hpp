@@ -176,6 +176,9 @@ __device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img
     BCR_SPAN_END(0, k0 / MP);
 }
 
+#ifdef BCR_PROBE_ON
+__device__ int bcr_probe_panel = -1;   // tools/potrf_probe.hip: stamp the chain kernel of this panel only (-1: every one)
+#endif
 // The dependent chain of the banded Cholesky in ONE launch per panel (one workgroup per problem): the diagonal
 // block k receives the contribution of panel k-1 here, in LDS, and is factored at once --
 //     P0 = A(k, k-1) L(k-1,k-1)^-T            (the first 128 rows of panel k-1; its band entries are final once
@@ -196,6 +199,10 @@ __global__ __launch_bounds__(BCR_PT) void hb3_chain_kernel(const double* __restr
     const int img = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     BCR_SPAN_RESET(0, k0 / MP);
     BCR_SPAN_BEGIN(0, k0 / MP);
+#ifdef BCR_PROBE_ON
+    if (tid == 0 && blockIdx.x == 0) bcr_probe_on = (bcr_probe_panel < 0 || k0 / MP == bcr_probe_panel) ? 1 : 0;
+    __syncthreads();
+#endif
     const double* Bi = band + (size_t)img * n * W;
     const double* Bd = Bi + (size_t)k0 * W;                   // A(k0+r, k0+c) = Bd[r + (W-1) c], r >= c
     if (k0 == 0) {

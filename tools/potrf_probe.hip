@@ -25,6 +25,11 @@ int main(int argc, char** argv) {
     HbBandSolver ch;
     if (ch.alloc(bw, n, O, st, false)) { printf("alloc: %s\n", ch.err.c_str()); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {   // stamp the chain kernel of a panel in the middle of the run (all streams busy), not the last one
+        const int mid = argc > 4 ? atoi(argv[4]) : ((n + 127) / 128) / 2;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bcr_probe_panel), &mid, sizeof(int)));
+        printf("chain-kernel stamps: panel %d\n", mid);
+    }
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, st));
         if (ch.factor(D, d_fail)) { printf("factor: %s\n", ch.err.c_str()); return 1; }
