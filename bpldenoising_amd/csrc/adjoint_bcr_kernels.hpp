@@ -223,7 +223,8 @@ __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld,
 // at S[(16*(c>>4) + (r&15)) + ld*(16*(r>>4) + (c&15))].  Returns true (in wave 0) on a non-positive pivot.
 //
 // The dependent chain is MP pivots long; everything else is kept off it.  Per block column p (16 columns):
-//   (1) all waves: left-looking update, tile (i, p) -= sum_{q<p} L_iq L_pq^T on the MFMA
+//   (1) all waves: tile (i, p) -= L_i,p-1 L_p,p-1^T on the MFMA -- only the newest block column; the older ones were
+//       applied right-looking by the waves 2.. while wave 0 factored (2)
 //   (2) wave 0: the whole block column -- up to 128 rows, lane l holds rows 16p + l and 16p + 64 + l -- is factored
 //       in registers: per pivot one rsqrt chain, then rank-1 updates with the pivot column's entries broadcast by
 //       readlane.  The rows below the diagonal tile come out as L directly (no product with an inverted diagonal tile).
@@ -237,19 +238,18 @@ __device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int M
     double* dinv = S + (size_t)ld * MP;   // 1 / L(r, r)
     bool bad = false;
     for (int p = 0; p < P; ++p) {
-        // (1) left-looking update of block column p
+        // (1) all waves: block column p receives the contribution of block column p-1 -- the only one still missing
+        //     (4 MFMAs per tile; the older ones were applied behind the panel factorisations, see (2))
         if (p > 0) {
             for (int i = p + wave; i < P; i += NW) {
                 bcr_d4 acc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)];
-                for (int q = 0; q < p; ++q) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double a = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
-                        const double b = S[(16 * p + lr) + ld * (16 * q + 4 * kk + lk)];
-                        acc = bcr_mfma(-a, b, acc);
-                    }
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = S[(16 * i + lr) + ld * (16 * (p - 1) + 4 * kk + lk)];
+                    const double b = S[(16 * p + lr) + ld * (16 * (p - 1) + 4 * kk + lk)];
+                    acc = bcr_mfma(-a, b, acc);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * p + lr)] = acc[g];
@@ -263,8 +263,29 @@ __device__ __forceinline__ bool bcr_potrf_lds_body(double* __restrict__ S, int M
             else bad |= bcr_panel_factor<false>(S, ld, MP, p, lane, dinv);
         } else if (wave == 1) {
             if (p >= 1) bcr_tile_inverse(S + 16 * (p - 1) + ld * (16 * (p - 1)), ld, lane, dinv + 16 * (p - 1));
-        } else if (p >= 2) {
-            for (int q = wave - 2; q < p - 2; q += NW - 2) bcr_winv_tile(S, ld, p - 2, q, lr, lk);
+        } else {
+            if (p >= 2)
+                for (int q = wave - 2; q < p - 2; q += NW - 2) bcr_winv_tile(S, ld, p - 2, q, lr, lk);
+            // right-looking, off the chain: block column p-1 applied to the lower tiles (i, j), j > p, of the rest
+            if (p >= 1) {
+                const int m = P - p - 1;   // tile rows / columns p+1 .. P-1
+                for (int t = wave - 2; t < m * (m + 1) / 2; t += NW - 2) {
+                    int a = 0, c = t;
+                    while (c > a) { c -= a + 1; ++a; }
+                    const int i = p + 1 + a, j = p + 1 + c;
+                    bcr_d4 acc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double x = S[(16 * i + lr) + ld * (16 * (p - 1) + 4 * kk + lk)];
+                        const double y = S[(16 * j + lr) + ld * (16 * (p - 1) + 4 * kk + lk)];
+                        acc = bcr_mfma(-x, y, acc);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)] = acc[g];
+                }
+            }
         }
         __syncthreads();
         BCR_PROBE(9 + 2 * p);
