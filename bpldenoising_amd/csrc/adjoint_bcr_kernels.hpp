@@ -321,13 +321,24 @@ __global__ __launch_bounds__(BCR_PT) void bcr_potrf_kernel(double* __restrict__ 
     __syncthreads();
     const bool bad = bcr_potrf_lds_body(S, MP);
     if (bad && lane == 0 && fail[img] == 0) fail[img] = j + 1;
-    for (int e = tid; e < MP * MP; e += BCR_PT) {
-        const int r = e % MP, c = e / MP;
-        double v = 0.0, w = 0.0;
-        if (r >= c) v = S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))];
-        if (c >= r) w = S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))];
-        Dj[e] = v;    // L^-1 (r, c)
-        DTj[e] = w;   // L^-T (r, c) = L^-1 (c, r)
+    // entry e = r + MP c of either array is W(hi, lo), hi = max(r, c), or zero: one LDS read per entry, in batches of
+    // 8 reads followed by their stores (a rolled loop pays the LDS latency once per entry)
+    for (int e0 = tid; e0 < MP * MP; e0 += 8 * BCR_PT) {
+        double w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = min(e0 + i * BCR_PT, MP * MP - 1), r = e % MP, c = e / MP;
+            const int hi = r > c ? r : c, lo = r > c ? c : r;
+            w[i] = S[(16 * (lo >> 4) + (hi & 15)) + ld * (16 * (hi >> 4) + (lo & 15))];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
+            if (e < MP * MP) {
+                Dj[e] = (r >= c) ? w[i] : 0.0;    // L^-1 (r, c)
+                DTj[e] = (c >= r) ? w[i] : 0.0;   // L^-T (r, c) = L^-1 (c, r)
+            }
+        }
     }
 }
 

@@ -167,10 +167,22 @@ __device__ __forceinline__ void hb2_potrf_finish(double* __restrict__ S, int img
     if (bad && lane == 0 && fail[img] == 0) fail[img] = k0 + 1;
     double* Li = Linv + ((size_t)img * npanel + k0 / MP) * MP * MP;
     double* LiT = LinvT + ((size_t)img * npanel + k0 / MP) * MP * MP;
-    for (int e = tid; e < MP * MP; e += BCR_PT) {
-        const int r = e % MP, c = e / MP;
-        if (r >= c) Li[e] = S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))];
-        if (c >= r) LiT[e] = S[(16 * (r >> 4) + (c & 15)) + ld * (16 * (c >> 4) + (r & 15))];
+    // entry e = r + 128 c of either array is W(hi, lo), hi = max(r, c): one LDS read per entry, in batches of 8 reads
+    // followed by their stores (a rolled loop pays the LDS latency 32 times)
+    for (int e0 = tid; e0 < MP * MP; e0 += 8 * BCR_PT) {
+        double w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
+            const int hi = r > c ? r : c, lo = r > c ? c : r;
+            w[i] = S[(16 * (lo >> 4) + (hi & 15)) + ld * (16 * (hi >> 4) + (lo & 15))];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i * BCR_PT, r = e % MP, c = e / MP;
+            if (r >= c) Li[e] = w[i];
+            if (c >= r) LiT[e] = w[i];
+        }
     }
     BCR_PROBE(6);
     BCR_SPAN_END(0, k0 / MP);
