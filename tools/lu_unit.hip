@@ -151,7 +151,8 @@ static bool run_case(int n, int bw, const std::vector<int>& offs, bool sym, int 
     printf("%-8s n %5d bw %4d sym %d O %d%s: max rel err %.2e %s\n", use_lu ? "LU" : "Cholesky", n, bw, (int)sym, O,
            (!use_lu && ch.twisted) ? " (twisted)" : "", worst, worst < 1e-10 ? "ok" : "FAILED");
     if (use_lu) lu.release(); else ch.release();
-    hipFree(d_pl); hipFree(d_pu); hipFree(d_v); hipFree(d_s); hipFree(d_fail); hipStreamDestroy(st);
+    for (void* q : {(void*)d_pl, (void*)d_pu, (void*)d_v, (void*)d_s, (void*)d_fail}) (void)hipFree(q);
+    (void)hipStreamDestroy(st);
     return worst < 1e-10;
 }
 
