@@ -517,8 +517,9 @@ def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
     ub, f = synth_batch(O, N, M, seed=77)
     amap = 0.05 + 0.1 * np.random.default_rng(9).random((N, M))
     res = []
-    for mode in ("value", "event"):
-        monkeypatch.setenv("BPLTV_HB_SYNC", mode)
+    for mode in ("value", "event", "single-stream"):   # the last: everything on one stream (the profiling aid)
+        monkeypatch.setenv("BPLTV_HB_SYNC", "event" if mode == "single-stream" else mode)
+        monkeypatch.setenv("BPLTV_HB_SINGLE_STREAM", "1" if mode == "single-stream" else "0")
         s = gpu_solver_cls(M, N, O)
         s.set_data(ub, f)
         _, _, g = s.evaluate(amap, 0.1, maxiter=300)
@@ -526,4 +527,4 @@ def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
         assert st["adjoint_method"] == "band-hbm" and st["adjoint_residual"] <= 1e-8
         res.append(g)
         s.close()
-    assert np.array_equal(res[0], res[1])
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
