@@ -6,11 +6,15 @@ torch.distributed.run, one rank per GPU).  One *step* = one pass of the hot path
 `denoise` of the resident batch with the reference's fixed iteration count (5000 PDHG iterations,
 /root/reference/src/TVLearningFunctionVec.jl:40), inputs already in HBM, result left in HBM.
 
-Workload (BASELINE.json configs[1] / north_star): 10 x 128 x 128 Float64 images, scalar alpha.
-Scaling: "weak" (default) -- every rank owns its own 10-image batch (images are independent ROF
-problems; no data-path collective); value = batches * iterations / time summed over ranks.
-`--scaling strong` shards ONE 10-image batch over the ranks (2,2,1,1,... for N = 8) and adds the
-per-evaluation all-reduce of [cost, grad] (`--evaluate`).
+Workload (BASELINE.json configs[1] / north_star): ONE batch of 10 x 128 x 128 Float64 images
+(faces_train_128_10), scalar alpha.  Scaling: "strong" (default, what north_star asks to be reported at
+1/2/4/8 GPUs) -- the images of that one batch are block-sharded over the ranks (2,2,1,1,1,1,1,1 for
+N = 8; images are independent ROF problems, no data-path collective; `--evaluate` adds the one
+all-reduce of [cost, grad] per evaluation); value = iterations/s of THAT batch.  The replica
+number (every rank solving its own 10-image batch, summed) is reported beside it as `weak_value`,
+never as `value`; `--scaling weak` makes it the timed workload.  `--multi-handle` times the
+single-process form instead: ONE bpltv_create_multi handle over N devices (worker thread per device
+and the RCCL collective inside the library) -- the form INTEGRATION.md gives the Julia caller.
 
 Rank 0 prints one JSON line with `roofline` (dominant kernel pdhg_tile_kernel, HBM-bound
 accounting: 56 B per pixel per iteration) and `cpu_baseline` (the oracle's C restatement timed on
@@ -165,6 +169,133 @@ def self_launch(n):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+def make_alpha(args, N, M):
+    import numpy as np
+    if args.alpha_map:
+        jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+        return 0.11 + 0.09 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
+    return args.alpha
+
+
+def binding_bound(launch_us, valu, hbm_frac_measured, redundancy):
+    """What actually bounds the kernel: the contractual HBM fraction of a temporally blocked
+    kernel is a figure of merit, not a bound.  Candidates: f64 VALU issue (counter-derived floor), HBM traffic as
+    measured, launch latency (what is left when neither explains the launch).  `frac_useful` divides by the
+    halo-recompute redundancy: the share of the launch spent on arithmetic the recurrence itself needs."""
+    cands = []
+    if valu:
+        cands.append(("valu_f64_issue", valu["frac"]))
+    if hbm_frac_measured is not None:
+        cands.append(("hbm", hbm_frac_measured))
+    if not cands:
+        return None
+    name, frac = max(cands, key=lambda c: c[1])
+    if frac < 0.5:
+        name = "launch_latency"   # neither issue nor bandwidth explains half of the launch: fixed launch + barrier latency
+    return {"bound": name, "frac": frac, "frac_useful": frac / redundancy if redundancy else None,
+            "candidates": {k: v for k, v in cands}}
+
+
+def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
+    """The `roofline` object for pdhg_tile_kernel from one solve's statistics."""
+    bytes_px = st["bytes_per_px_iter"]
+    bytes_per_launch = bytes_px * M * N * O_local * (iters / max(st["launches"], 1))
+    achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+    # Counter-derived figures are NOT measured by this run: they are the committed summaries of separate
+    # rocprofv3 --pmc passes of the same command (profiles/traffic.json, written by tools/refresh_profiles.py)
+    # and are labelled with their source.
+    wl_key = "%dx%dx%d %s" % (O_local, N, M, "map" if bytes_px in (64.0, 32.0) else "scalar")
+    traffic, traffic_src, valu_instr = None, None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf) and not f32:   # the committed counters are those of the Float64 kernel
+        try:
+            tj = json.load(open(tf)).get("workloads", {}).get(wl_key)
+            if tj and tj.get("tile_iters") == st["tile_iters"] and tj.get("tiles") == st["tiles"]:
+                traffic = tj.get("hbm_bytes_per_launch")
+                valu_instr = tj.get("valu_wave_instructions_per_launch")
+                traffic_src = "profiles/traffic.json[%s] (%s)" % (wl_key, tj.get("round", "?"))
+        except Exception:
+            traffic = None
+    # the temporal blocking trades HBM traffic for redundant halo arithmetic, so beside the contractual HBM figure
+    # the line carries the redundancy and the f64 VALU issue floor: wave-instructions * 4 cycles (a wave64 f64 op
+    # occupies a SIMD for 4 cycles) / (CUs * 4 SIMDs) / 2.4 GHz.
+    nit_avg = iters / max(st["launches"], 1)
+    computed_px_it = st["tiles"] * st["region_i"] * st["region_j"] * nit_avg
+    useful_px_it = M * N * O_local * nit_avg
+    redundancy = computed_px_it / useful_px_it
+    valu = None
+    if valu_instr:
+        floor_us = valu_instr * 4.0 / (256 * 4) / 2.4e3
+        valu = {"bound": "valu_f64_issue", "wave_instructions_per_launch": valu_instr,
+                "instr_per_computed_px_iter": valu_instr * 64.0 / computed_px_it,
+                "floor_us": floor_us, "frac": floor_us / launch_us, "source": traffic_src,
+                "note": "upper estimate of the issue floor: every VALU instruction priced at the f64 rate"}
+    measured_hbm_frac = (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None
+    return {"bound": "hbm", "bound_note": "contractual: algorithmic bytes (SURVEY 8d: 56/64 B per pixel-iteration) / launch time; "
+                                          "the fused kernel touches HBM once per tile_iters iterations, see `binding`",
+            "kernel": "pdhg_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "measured_hbm_frac": measured_hbm_frac,   # counter traffic / launch time / peak: the HBM share actually used
+            "binding": binding_bound(launch_us, valu, measured_hbm_frac, redundancy),
+            "redundancy": redundancy,   # computed / useful pixel-iterations (halo recompute)
+            "region": [st["region_i"], st["region_j"]], "valu_f64": valu,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
+            "avg_kernel_us_serialized": kernel_us,
+            "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
+            "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
+            "bytes_per_px_iter": bytes_px}
+
+
+def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, evaluate_once, data):
+    """One more workload measured outside the timed region of the default run (N = 1), so that the driver's record
+    holds it: the reference's default num_samples = 1 (/root/reference/src/BPLDenoising.jl:313) and the per-GPU
+    share of BASELINE config 5.  Inputs resident in HBM; `value` = PDHG iterations/s of that batch."""
+    import numpy as np
+
+    class A:   # the few fields make_alpha / roofline_of read
+        pass
+    a = A(); a.alpha_map = alpha_map; a.alpha = 0.1
+    ub, f, label = load_batch(data, O, size, size, 20211004)
+    alpha = make_alpha(a, size, size)
+    s = TVSolver(size, size, O, device=torch.cuda.current_device())
+    t_ub, t_f = torch.from_numpy(ub).cuda(), torch.from_numpy(f).cuda()
+    torch.cuda.synchronize()
+    s.set_data_device(t_ub.data_ptr(), t_f.data_ptr())
+    s.denoise(alpha, fetch=False, maxiter=iters)
+    torch.cuda.synchronize()
+    ev_ms, ev_l = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.denoise(alpha, fetch=False, maxiter=iters)
+        st = s.stats(); ev_ms += st["pdhg_ms"]; ev_l += st["launches"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launch_us = 1e3 * ev_ms / max(ev_l, 1)
+    out = {"workload": "%dx%dx%d f64, %s alpha, %d PDHG iterations per step, data %s" % (
+               O, size, size, "per-pixel" if alpha_map else "scalar", iters, label),
+           "value": steps * iters / dt, "unit": "PDHG iterations/s of that batch", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "tile_iters": st["tile_iters"], "tiles_per_launch": st["tiles"],
+           "roofline": roofline_of(a, st, size, size, O, iters, launch_us, None, False)}
+    if evaluate_once:
+        part = torch.zeros(1 + (size * size if alpha_map else 1), dtype=torch.float64, device="cuda")
+        best = None
+        for _ in range(2):   # the first call allocates the adjoint workspace
+            t1 = time.perf_counter()
+            s.evaluate_device(alpha, 0.1, part.data_ptr(), maxiter=iters)
+            torch.cuda.synchronize()
+            e_ms = 1e3 * (time.perf_counter() - t1)
+            s3 = s.stats()
+            if best is None or e_ms < best["evaluate_ms"]:
+                best = {"evaluate_ms": e_ms, "pdhg_ms": s3["pdhg_ms"], "adjoint_ms": s3["adjoint_ms"],
+                        "adjoint_method": s3["adjoint_method"], "adjoint_residual": s3["adjoint_residual"],
+                        "adjoint_chunks": s3["adjoint_chunks"]}
+        out["learning_function"] = best
+    s.close()
+    del t_ub, t_f
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +306,11 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--alpha-map", action="store_true", help="spatially varying alpha (64 B/px/iter)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): ONE --images batch sharded over the ranks (north_star); weak: every rank its own batch")
+    ap.add_argument("--multi-handle", action="store_true",
+                    help="one process, one bpltv_create_multi handle over --gpus devices (the Julia drop-in form); "
+                         "run as `python bench.py --gpus N --multi-handle`, no launcher")
     ap.add_argument("--evaluate", action="store_true", help="time full evaluate (loss + adjoint gradient + all-reduce)")
     ap.add_argument("--tile-iters", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
@@ -184,16 +319,17 @@ def main():
                          "never the headline; the line then says dtype f32 and counts 28/32 B per pixel-iteration")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / weak_value measured outside the timed region")
     ap.add_argument("--chains", type=int, default=0, help="independent launch chains (0 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a 1-GPU rehearsal)")
-    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank / shard uses device 0")
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU sample (0 = auto)")
     ap.add_argument("--data", default="auto",
                     help="auto (faces_train_128_10 at --size 128, else synthetic) | faces_train_128_10 | "
                          "faces_val_128_10 | cameraman_128_10 | circle_128_10 | synthetic")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.multi_handle:
         sys.exit(self_launch(args.gpus))
 
     import numpy as np
@@ -203,7 +339,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not args.multi_handle:
         if world == 1 and args.gpus > 1:
             print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
             sys.exit(2)
@@ -234,47 +370,14 @@ def main():
     from bpldenoising_amd import TVSolver, shard_range
 
     M = N = args.size
-    if args.scaling == "weak":
-        O_local, seed = args.images, 20211004 + rank
-        lo = 0
-    else:
-        lo, hi = shard_range(args.images, world, rank)
-        O_local, seed = hi - lo, 20211004
-    ub_full, f_full, data_label = load_batch(args.data, args.images, N, M, seed)
-    ub, f = (ub_full, f_full) if args.scaling == "weak" else (ub_full[lo:lo + O_local], f_full[lo:lo + O_local])
-    if args.alpha_map:
-        jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
-        alpha = 0.11 + 0.09 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
-    else:
-        alpha = args.alpha
-
-    solver = None
+    gloo = world > 1 and args.backend != "nccl"
     kw = dict(maxiter=args.iters, tile_iters=args.tile_iters, use_graph=0 if args.no_graph else 1)
     if args.variant:
         kw["variant"] = args.variant
     if args.chains:
         kw["chains"] = args.chains
-    gloo = world > 1 and args.backend != "nccl"
-    if O_local > 0:
-        solver = TVSolver(M, N, O_local, device=local_rank, dtype=32 if args.f32 else 64)
-        t_ub = torch.from_numpy(ub).cuda()
-        t_f = torch.from_numpy(f).cuda()
-        torch.cuda.synchronize()
-        solver.set_data_device(t_ub.data_ptr(), t_f.data_ptr())  # inputs resident in HBM
-    part = torch.zeros(2 if not args.alpha_map else 1 + M * N, dtype=torch.float64, device="cuda")
-
-    def step():
-        if args.evaluate:
-            part.zero_()
-            if solver is not None:
-                solver.evaluate_device(alpha, 0.1, part.data_ptr(), **kw)
-            if world > 1:
-                if gloo:
-                    pc = part.cpu(); dist.all_reduce(pc); part.copy_(pc)
-                else:
-                    dist.all_reduce(part)
-        elif solver is not None:
-            solver.denoise(alpha, fetch=False, **kw)
+    alpha = make_alpha(args, N, M)
+    npar = 1 + (M * N if args.alpha_map else 1)
 
     def fence():
         torch.cuda.synchronize()
@@ -282,102 +385,186 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev_ms, ev_launches, ev_steps = 0.0, 0, []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if solver is not None:
+    def timed(step, steps, warmup, stats_of=None):
+        """W untimed steps, then exactly `steps` steps between two fences; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        fence()
+        ev_ms, ev_l, ev_steps = 0.0, 0, []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            if stats_of is not None:
+                st = stats_of()
+                ev_ms += st["pdhg_ms"]; ev_steps.append(st["pdhg_ms"]); ev_l += st["launches"]   # HIP events, library stream
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), ev_ms, ev_l, ev_steps
+
+    def make_solver(ub, f, O_local):
+        s = TVSolver(M, N, O_local, device=local_rank, dtype=32 if args.f32 else 64)
+        t_ub, t_f = torch.from_numpy(ub).cuda(), torch.from_numpy(f).cuda()
+        torch.cuda.synchronize()
+        s.set_data_device(t_ub.data_ptr(), t_f.data_ptr())  # inputs resident in HBM (copied device to device)
+        return s
+
+    def make_step(s, part):
+        def step():
+            if args.evaluate:
+                part.zero_()
+                if s is not None:
+                    s.evaluate_device(alpha, 0.1, part.data_ptr(), **kw)
+                if world > 1:
+                    if gloo:
+                        pc = part.cpu(); dist.all_reduce(pc); part.copy_(pc)
+                    else:
+                        dist.all_reduce(part)
+            elif s is not None:
+                s.denoise(alpha, fetch=False, **kw)
+        return step
+
+    multi_info = None
+    if args.multi_handle:
+        # ---- ONE process, ONE handle over args.gpus devices (bpltv_create_multi): the drop-in form ----------------
+        if rank != 0:   # launched under torchrun anyway: the other ranks only wait for rank 0 at the final barrier
+            dist.barrier(); dist.destroy_process_group()
+            return
+        ub_full, f_full, data_label = load_batch(args.data, args.images, N, M, 20211004)
+        ndev = torch.cuda.device_count()
+        if args.one_device:
+            solver = TVSolver(M, N, args.images, devices=[0] * args.gpus, dtype=32 if args.f32 else 64)
+        else:
+            solver = TVSolver(M, N, args.images, ngpus=args.gpus, dtype=32 if args.f32 else 64)
+        solver.set_data(ub_full, f_full)   # each device copies its slice; resident afterwards
+        O_local = args.images
+
+        def step():
+            if args.evaluate:
+                solver.evaluate(alpha, 0.1, fetch_u=False, **kw)
+            else:
+                solver.denoise(alpha, fetch=False, **kw)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        ev_ms, ev_launches, ev_steps = 0.0, 0, []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()   # the ABI call returns when every device is quiescent (SURVEY 8b threading)
             st = solver.stats()
-            ev_ms += st["pdhg_ms"]          # HIP events on the library's own stream
-            ev_steps.append(st["pdhg_ms"])
-            ev_launches += st["launches"]
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    T = float(tmax.item())
+            ev_ms += st["pdhg_ms"]; ev_steps.append(st["pdhg_ms"]); ev_launches += st["launches"]
+        T = time.perf_counter() - t0
+        st = solver.stats()
+        n_eff = st["shards"]
+        multi_info = {"mode": "bpltv_create_multi (single process, worker thread per device, RCCL inside the library)",
+                      "devices_visible": ndev, "ngpus": st["ngpus"], "shards": st["shards"],
+                      "nccl_ranks_reported_by_rccl": st["nccl_ranks"],   # ncclCommCount of the handle's communicator
+                      "collective": st["collective"], "collective_ms": st["collective_ms"],
+                      "shard_ranges": [list(shard_range(args.images, n_eff, k)) for k in range(n_eff)]}
+        scaling, world_out = "strong", args.gpus
+        weak = None
+        rank_info = None
+    else:
+        # ---- one process per GPU (torch.distributed; the driver's launch) ------------------------------------------
+        if args.scaling == "weak":
+            lo, O_local, seed = 0, args.images, 20211004 + rank
+        else:
+            lo, hi = shard_range(args.images, world, rank)
+            O_local, seed = hi - lo, 20211004
+        ub_full, f_full, data_label = load_batch(args.data, args.images, N, M, seed)
+        ub, f = (ub_full, f_full) if args.scaling == "weak" else (ub_full[lo:lo + O_local], f_full[lo:lo + O_local])
+        solver = make_solver(ub, f, O_local) if O_local > 0 else None
+        part = torch.zeros(npar, dtype=torch.float64, device="cuda")
+        T, ev_ms, ev_launches, ev_steps = timed(make_step(solver, part), args.steps, args.warmup,
+                                                (lambda: solver.stats()) if solver is not None else None)
+        scaling, world_out = args.scaling, world
+        # what every rank did, and what the collective library itself says about the job
+        rank_info = None
+        if world > 1:
+            mine = torch.tensor([float(torch.cuda.current_device()), float(lo), float(lo + O_local),
+                                 ev_ms / max(args.steps, 1)], dtype=torch.float64, device="cpu" if gloo else "cuda")
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            rank_info = [{"rank": r, "device": int(t[0].item()), "images": [int(t[1].item()), int(t[2].item())],
+                          "pdhg_event_ms_per_step": float(t[3].item())} for r, t in enumerate(allr)]
+        # the replica figure (every rank its own full batch, summed): reported beside `value`, never as it
+        weak = None
+        if world > 1 and args.scaling == "strong" and not args.no_extras:
+            ubw, fw, _ = load_batch(args.data, args.images, N, M, 20211004 + rank)
+            sw = make_solver(ubw, fw, args.images)
+            wsteps = max(1, min(args.steps, 5))
+            Tw, _, _, _ = timed(make_step(sw, torch.zeros(npar, dtype=torch.float64, device="cuda")), wsteps, 1)
+            weak = {"weak_value": world * wsteps * args.iters / Tw, "weak_ms_per_step": 1e3 * Tw / wsteps, "weak_steps": wsteps}
+            sw.close()
 
     if rank == 0:
+        if solver is None:
+            raise SystemExit("bench.py: rank 0 holds no image (images < 1?)")
         st = solver.stats()
-        batches = world if args.scaling == "weak" else 1
+        batches = world_out if scaling == "weak" else 1
         value = batches * args.steps * args.iters / T
-        bytes_px = st["bytes_per_px_iter"]
         launch_us = 1e3 * ev_ms / max(ev_launches, 1)
         # isolated duration of one launch (chains replayed one after the other), the number a
         # rocprofv3 --kernel-trace of this command reports per kernel
         ser_ms, ser_l = 0.0, 0
-        if not args.evaluate:
+        if not args.evaluate and not args.multi_handle:
             for _ in range(3):
                 solver.denoise(alpha, fetch=False, serialize_chains=1, **kw)
                 s2 = solver.stats(); ser_ms += s2["pdhg_ms"]; ser_l += s2["launches"]
         kernel_us = 1e3 * ser_ms / max(ser_l, 1) if ser_l else None
-        bytes_per_launch = bytes_px * M * N * O_local * (args.iters / max(st["launches"], 1))
-        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        # Counter-derived figures are NOT measured by this run: they are the committed summaries of separate
-        # rocprofv3 --pmc passes of the same command (profiles/traffic.json, written by tools/refresh_profiles.py)
-        # and are labelled with their source.
-        wl_key = "%dx%dx%d %s" % (O_local, N, M, "map" if args.alpha_map else "scalar")
-        traffic, traffic_src, valu_instr = None, None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf)).get("workloads", {}).get(wl_key)
-                if args.f32:
-                    tj = None   # the committed counters are those of the Float64 kernel
-                if tj and tj.get("tile_iters") == st["tile_iters"] and tj.get("tiles") == st["tiles"]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    valu_instr = tj.get("valu_wave_instructions_per_launch")
-                    traffic_src = "profiles/traffic.json[%s] (%s)" % (wl_key, tj.get("round", "?"))
-            except Exception:
-                traffic = None
-        # What actually bounds the kernel: the temporal blocking trades HBM traffic for redundant
-        # halo arithmetic, so beside the contractual HBM figure the line carries the redundancy and the f64
-        # VALU issue floor: wave-instructions * 4 cycles (a wave64 f64 op occupies a SIMD for 4 cycles)
-        # / (CUs * 4 SIMDs) / 2.4 GHz.
-        nit_avg = args.iters / max(st["launches"], 1)
-        computed_px_it = st["tiles"] * st["region_i"] * st["region_j"] * nit_avg
-        useful_px_it = M * N * O_local * nit_avg
-        valu = None
-        if valu_instr:
-            floor_us = valu_instr * 4.0 / (256 * 4) / 2.4e3
-            valu = {"bound": "valu_f64_issue", "wave_instructions_per_launch": valu_instr,
-                    "instr_per_computed_px_iter": valu_instr * 64.0 / computed_px_it,
-                    "floor_us": floor_us, "frac": floor_us / launch_us, "source": traffic_src,
-                    "note": "upper estimate of the issue floor: every VALU instruction priced at the f64 rate"}
+        # the roofline is that of rank 0's kernel: its launch processes rank 0's images (the largest shard)
+        O_roof = (shard_range(args.images, st["shards"], 0)[1] if args.multi_handle else O_local)
+        if args.multi_handle:
+            st_roof = dict(st); st_roof["tiles"] = st["tiles"] * O_roof // max(args.images, 1)
+        else:
+            st_roof = st
         out = {
             "metric": "PDHG iters/sec (batched 128x128 images)",
             "value": value,
-            "unit": "PDHG iterations/s of a %dx%dx%d %s batch%s" % (
-                args.images, N, M, "f32 (opt-in, narrower than the reference)" if args.f32 else "f64", " per GPU, summed over GPUs" if args.scaling == "weak" and world > 1 else ""),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "PDHG iterations/s of %s %dx%dx%d %s batch%s" % (
+                "ONE" if scaling == "strong" else "a", args.images, N, M,
+                "f32 (opt-in, narrower than the reference)" if args.f32 else "f64",
+                " sharded over the GPUs" if scaling == "strong" and world_out > 1 else
+                (" per GPU, summed over GPUs" if scaling == "weak" and world_out > 1 else "")),
+            "n_gpus": world_out, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * T / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32" if args.f32 else "f64", "data": data_label,
             "config": {"workload": "%dx%dx%d %s batch, %s alpha, %d PDHG iterations per step (%s)" % (
                            args.images, N, M, "f32" if args.f32 else "f64", "per-pixel" if args.alpha_map else "scalar", args.iters,
                            "evaluate: loss + adjoint gradient + all-reduce" if args.evaluate else "denoise"),
-                       "images_per_gpu": O_local, "tile_iters": st["tile_iters"], "tiles_per_launch": st["tiles"],
+                       "images_per_gpu": O_roof, "tile_iters": st["tile_iters"], "tiles_per_launch": st_roof["tiles"],
                        "launches_per_step": st["launches"], "hipgraph": bool(st["graph_used"]),
-                       "parallelism": "images sharded, dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "pdhg_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "redundancy": computed_px_it / useful_px_it,   # computed / useful pixel-iterations (halo recompute)
-                         "region": [st["region_i"], st["region_j"]], "valu_f64": valu,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
-                         "avg_kernel_us_serialized": kernel_us,
-                         "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
-                         "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
-                         "bytes_per_px_iter": bytes_px},
+                       "parallelism": ("images of one batch sharded, dp%d" if scaling == "strong" else "one batch per GPU, dp%d") % world_out},
+            "roofline": roofline_of(args, st_roof, M, N, O_roof, args.iters, launch_us, kernel_us, args.f32),
             "pdhg_event_ms_per_step": ev_ms / args.steps,
             "pdhg_event_ms_median": float(np.median(ev_steps)) if ev_steps else None,   # SURVEY 8d: median of the repeats
         }
-        if world == 1 and not args.evaluate and M * N * O_local <= 16 * 128 * 128:
+        if world_out > 1:
+            comm = {"form": "torch.distributed, one process per GPU" if not args.multi_handle else "in-library",
+                    "world_size": dist.get_world_size() if world > 1 else 1,
+                    "backend": (dist.get_backend() if world > 1 else None)}
+            if world > 1 and args.backend == "nccl":
+                try:
+                    comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception:
+                    pass
+            comm["collective_per_step"] = ("all_reduce of [cost, grad] (%d doubles)" % npar) if args.evaluate else "none (denoise: images are independent)"
+            out["comm"] = comm
+            out["ranks"] = rank_info
+        if multi_info:
+            out["multi_handle"] = multi_info
+        if weak:
+            out.update(weak)
+            out["weak_note"] = "replicas: every rank solves its own %d-image batch; sum over ranks; NOT `value`" % args.images
+        default_wl = (world_out == 1 and not args.evaluate and not args.multi_handle and not args.f32 and not args.alpha_map
+                      and M == 128 and args.images == 10)
+        if world_out == 1 and not args.evaluate and not args.multi_handle and M * N * O_local <= 16 * 128 * 128:
             # outside the timed region: one full learning-function evaluation on the same resident batch
             # (PDHG + loss + adjoint gradient), the unit of work of the outer trust-region loop
+            part = torch.zeros(npar, dtype=torch.float64, device="cuda")
             tt, pm, am = [], [], []
             for _ in range(3):
                 t1 = time.perf_counter()
@@ -388,7 +575,17 @@ def main():
             out["learning_function"] = {"evaluate_ms": min(tt), "pdhg_ms": min(pm), "adjoint_ms": min(am),
                                         "adjoint_method": s3["adjoint_method"], "adjoint_residual": s3["adjoint_residual"],
                                         "note": "tv_op_learning_function on the same batch, best of 3, not part of `value`"}
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
+        if default_wl and not args.no_extras:
+            # extra workloads of the default run, outside the timed region: the reference's
+            # default num_samples = 1, and one GPU's share of BASELINE config 5 (8 x 1024^2, per-pixel alpha)
+            try:
+                out["extra_workloads"] = {
+                    "single_image": extra_workload(TVSolver, torch, "single_image", 1, 128, args.iters, 5, False, True, "faces_train_128_10"),
+                    "config5_share": extra_workload(TVSolver, torch, "config5_share", 8, 1024, 400, 3, True, True, "synthetic"),
+                }
+            except Exception as e:   # never lose the headline line to an extra
+                out["extra_workloads"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_cpu_baseline and world_out == 1:  # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, f_full, ub_full, alpha, N, M)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -26,6 +26,8 @@ class BpltvParams(C.Structure):
         ("refine", C.c_int),
         ("deterministic", C.c_int),
         ("reserved", C.c_int * 5),
+        ("init", C.c_int), ("order", C.c_int),
+        ("opnorm", C.c_double),
     ]
 
 
@@ -43,12 +45,14 @@ class BpltvStats(C.Structure):
         ("reg_gradient_used", C.c_int), ("ngpus", C.c_int),
         ("shards", C.c_int), ("collective", C.c_int),
         ("collective_ms", C.c_double),
-        ("reserved", C.c_int * 4),
+        ("nccl_ranks", C.c_int), ("hb_sync", C.c_int), ("adjoint_chunks", C.c_int),
+        ("reserved", C.c_int * 1),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
-        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm"}.get(self.adjoint_method, "")
+        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm", 4: "band-lu", 5: "nd"}.get(self.adjoint_method, "")
+        d["hb_sync"] = {0: "", 1: "event", 2: "value"}.get(self.hb_sync, "")
         d["collective"] = {0: "none", 1: "ncclAllReduce", 2: "ncclAllGather+ordered sum", 3: "host sum"}.get(self.collective, "")
         return d
 

@@ -81,26 +81,32 @@ struct GraphKey {
     double rho, tau0, sigma0;
     int accel, dbg, nimg;
     const void* state;
+    const void* tab;   // step table (one per (maxiter, steps, L, dual-first shift): TabKey)
+    int from_state;    // 1: the sequence starts from a prepared state (params.init / order), not from x = f, y = 0
     bool operator<(const GraphKey& o) const {
-        return std::tie(maxiter, T, variant, am, an, chains, rho, tau0, sigma0, accel, dbg, nimg, state) <
-               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.chains, o.rho, o.tau0, o.sigma0, o.accel, o.dbg, o.nimg, o.state);
+        return std::tie(maxiter, T, variant, am, an, chains, rho, tau0, sigma0, accel, dbg, nimg, state, tab, from_state) <
+               std::tie(o.maxiter, o.T, o.variant, o.am, o.an, o.chains, o.rho, o.tau0, o.sigma0, o.accel, o.dbg, o.nimg, o.state, o.tab, o.from_state);
     }
 };
 
 struct TabKey {
     int maxiter, accel;
     double tau0, sigma0;
-    double L2;   // squared operator-norm bound the steps are divided by: 8 (TV), 18 (sum of regularisers)
+    double L;    // operator-norm estimate the steps are divided by: sqrt(8) (TV), sqrt(18) (sum of regularisers),
+                 // or params.opnorm
+    int shift;   // 1: row k carries sigma_{k+1} (dual-first order: the dual step of iteration k+1 follows the
+                 // primal step of iteration k inside the fused kernel)
     bool operator<(const TabKey& o) const {
-        return std::tie(maxiter, accel, tau0, sigma0, L2) < std::tie(o.maxiter, o.accel, o.tau0, o.sigma0, o.L2);
+        return std::tie(maxiter, accel, tau0, sigma0, L, shift) < std::tie(o.maxiter, o.accel, o.tau0, o.sigma0, o.L, o.shift);
     }
 };
 
 struct SrGraphKey {
     int maxiter, T, am, an, accel;
     double rho, tau0, sigma0;
+    const void* tab;
     bool operator<(const SrGraphKey& o) const {
-        return std::tie(maxiter, T, am, an, accel, rho, tau0, sigma0) < std::tie(o.maxiter, o.T, o.am, o.an, o.accel, o.rho, o.tau0, o.sigma0);
+        return std::tie(maxiter, T, am, an, accel, rho, tau0, sigma0, tab) < std::tie(o.maxiter, o.T, o.am, o.an, o.accel, o.rho, o.tau0, o.sigma0, o.tab);
     }
 };
 
@@ -227,7 +233,7 @@ int ensure(bpltv_t* h, double** p, size_t* cap, size_t need) {
 
 void fill_table(const TabKey& k, std::vector<double>& tab) {
     // oracle/bpltv_oracle.c: bplo_step_table_L (same operations, same order)
-    const double L = std::sqrt(k.L2);
+    const double L = k.L;
     double tau = k.tau0 / L, sigma = k.sigma0 / L;
     const double gamma = 1.0;
     tab.assign((size_t)TAB_STRIDE * (k.maxiter > 0 ? k.maxiter : 1), 0.0);
@@ -243,11 +249,15 @@ void fill_table(const TabKey& k, std::vector<double>& tab) {
             tau = tau * omega;
             sigma = sigma / omega;
         }
+        if (k.shift) r[1] = sigma;   // sigma_{it+1}
     }
 }
 
-int get_table(bpltv_t* h, const bpltv_params& p, double** out, double L2 = 8.0) {
-    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, L2};
+// operator-norm estimate of a solve: params.opnorm, or the model's bound (sqrt(8) TV, sqrt(18) sum of regularisers)
+double opnorm_of(const bpltv_params& p, double L2_default) { return p.opnorm > 0.0 ? p.opnorm : std::sqrt(L2_default); }
+
+int get_table(bpltv_t* h, const bpltv_params& p, double** out, double L2 = 8.0, int shift = 0) {
+    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, opnorm_of(p, L2), shift};
     auto it = h->tabs.find(k);
     if (it != h->tabs.end()) {
         *out = it->second;
@@ -276,7 +286,7 @@ void cvt_to_f64(bpltv_t* h, const float* src, double* dst, size_t n) {
 void drop_graphs(bpltv_t* h);
 // step table rounded to float (the oracle's bplo_pdhg_f32 rounds the same f64 table)
 int get_table32(bpltv_t* h, const bpltv_params& p, float** out) {
-    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, 8.0};
+    TabKey k{p.maxiter, p.accel ? 1 : 0, p.tau0, p.sigma0, opnorm_of(p, 8.0), 0};
     auto it = h->tabs32.find(k);
     if (it != h->tabs32.end()) {
         *out = it->second;
@@ -440,7 +450,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
 
 // Build one hipGraph per chain (image group): maxiter iterations as a linear launch sequence.
 // The chains are replayed concurrently, each on its own stream (= its own hardware queue).
-int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab,
+int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab, int niter, bool from_state,
                  std::vector<hipGraphExec_t>* out) {
     const Variant& V = kVariants[pl.variant];
     const int tilesPerImg = pl.nTi * pl.nTj;
@@ -451,8 +461,8 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         hipGraph_t g = nullptr;
         HIPCHK(h, hipGraphCreate(&g, 0));
         hipGraphNode_t prev = nullptr;
-        int cur = 0;
-        for (int it = 0; it < p.maxiter; it += pl.T) {
+        int cur = from_state ? 1 : 0;   // a prepared start lives in set 1; launch 0 always writes set 0
+        for (int it = 0; it < niter; it += pl.T) {
             PdhgArgs a;
             a.f = pdhg_f(h); a.alpha = pdhg_alpha(h); a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
@@ -464,11 +474,11 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             a.dbg = p.reserved[3];
 #endif
             const int nxt = (it == 0) ? 0 : 1 - cur;
-            a.first = (it == 0) ? 1 : 0;
+            a.first = (it == 0 && !from_state) ? 1 : 0;
             a.xin = pdhg_state(h, cur, 0); a.y1in = pdhg_state(h, cur, 1); a.y2in = pdhg_state(h, cur, 2);
             a.xout = pdhg_state(h, nxt, 0); a.y1out = pdhg_state(h, nxt, 1); a.y2out = pdhg_state(h, nxt, 2);
             a.it0 = it;
-            a.nit = std::min(pl.T, p.maxiter - it);
+            a.nit = std::min(pl.T, niter - it);
             void* kargs[] = {&a};
             hipKernelNodeParams kp;
             std::memset(&kp, 0, sizeof(kp));
@@ -505,7 +515,7 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
 // Enqueue PDHG iterations [it0, it1) on the stream.  *buf: state set holding the current iterate
 // (ignored when it0 == 0), updated to the set holding the result.
 int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab, int it0, int it1,
-                 int* buf, int* launches) {
+                 int* buf, int* launches, bool from_state = false) {
     const Variant& V = kVariants[pl.variant];
     PdhgArgs a;
     a.f = pdhg_f(h);
@@ -525,7 +535,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     for (int it = it0; it < it1; it += pl.T) {
         const int nit = std::min(pl.T, it1 - it);
         const int nxt = (it == 0) ? 0 : 1 - cur;
-        a.first = (it == 0) ? 1 : 0;
+        a.first = (it == 0 && !from_state) ? 1 : 0;
         a.xin = pdhg_state(h, cur, 0); a.y1in = pdhg_state(h, cur, 1); a.y2in = pdhg_state(h, cur, 2);
         a.xout = pdhg_state(h, nxt, 0); a.y1out = pdhg_state(h, nxt, 1); a.y2out = pdhg_state(h, nxt, 2);
         a.it0 = it;
@@ -568,6 +578,14 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     Plan pl;
     int rc = make_plan(h, p, &pl);
     if (rc) return rc;
+    // params.init / order (the choices of op_denoise_pdps the reference does not pin): the sequence starts from a
+    // prepared state (pdhg_init_kernel) instead of x = f, y = 0; dual-first order = the dual step of iteration 0 in
+    // that kernel, maxiter - 1 fused iterations on a table whose row k carries sigma_{k+1}, and the closing primal
+    // step (pdhg_xstep_kernel).  Checker: bplo_pdhg_opts.
+    const bool from_state = (p.init != 0 || p.order != 0);
+    const int main_iters = p.maxiter - (p.order ? 1 : 0);
+    if (from_state && h->dtype == 32)
+        return set_err(h, BPLTV_E_UNSUPPORTED, "params.init / params.order are implemented for dtype = 64 handles");
     double* d_tab = nullptr;
     if (h->dtype == 32) {
         float* t32 = nullptr;
@@ -575,7 +593,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
         if (!rc && p.maxiter > 0) rc = f32_prepare(h);
         d_tab = reinterpret_cast<double*>(t32);
     } else {
-        rc = get_table(h, p, &d_tab);
+        rc = get_table(h, p, &d_tab, 8.0, p.order ? 1 : 0);
     }
     if (rc) return rc;
     h->st.tile_iters = pl.T;
@@ -587,9 +605,9 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->st.graph_used = 0;
     h->st.last_gap = -1.0;
     int buf = 0, launches = 0;
-    if (p.maxiter == 0) {  // u = f
+    if (p.maxiter == 0) {  // u = x0 = f (params.init = 1: 0)
         for (int c = 0; c < 3; ++c) {
-            if (c == 0) {
+            if (c == 0 && !p.init) {
                 for (int r = 0; r < h->cur_nimg / h->O; ++r)
                     HIPCHK(h, hipMemcpyAsync(h->cur_state[0][0] + (size_t)r * h->tot, h->d_f, h->tot * sizeof(double),
                                              hipMemcpyDeviceToDevice, h->stream));
@@ -604,20 +622,29 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
         return BPLTV_OK;
     }
     const bool chunked = p.check_every > 0;
+    const size_t total = (size_t)h->cur_nimg * h->npx;
+    const unsigned gtot = (unsigned)((total + 255) / 256);
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (from_state) {
+        hipLaunchKernelGGL(pdhg_init_kernel, dim3(gtot), dim3(256), 0, h->stream, h->d_f, h->d_alpha, h->last_am, h->last_an,
+                           h->M, h->N, h->O, h->cur_astride, total, p.init ? 1 : 0, p.order ? 1 : 0,
+                           p.sigma0 / opnorm_of(p, 8.0), p.rho, h->cur_state[1][0], h->cur_state[1][1], h->cur_state[1][2]);
+        HIPCHK(h, hipGetLastError());
+        buf = 1;
+    }
     if (!chunked) {
-        bool done = false;
-        if (p.use_graph) {
-            GraphKey key{p.maxiter, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)pdhg_state(h, 0, 0)};
+        bool done = main_iters == 0;
+        if (p.use_graph && !done) {
+            GraphKey key{main_iters, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)pdhg_state(h, 0, 0), (const void*)d_tab, from_state ? 1 : 0};
             auto it = h->graphs.find(key);
-            const int nl = (p.maxiter + pl.T - 1) / pl.T;
+            const int nl = (main_iters + pl.T - 1) / pl.T;
             if (it == h->graphs.end() && h->graphs.size() >= 16) {  // bounded cache
                 drop_graphs(h);
                 it = h->graphs.end();
             }
             if (it == h->graphs.end() && nl <= 50000) {  // longer sequences are launched eagerly
                 std::vector<hipGraphExec_t> ex;
-                if (build_graphs(h, p, pl, d_tab, &ex) == BPLTV_OK && !ex.empty()) {
+                if (build_graphs(h, p, pl, d_tab, main_iters, from_state, &ex) == BPLTV_OK && !ex.empty()) {
                     h->graphs[key] = ex;
                     it = h->graphs.find(key);
                 }
@@ -653,7 +680,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             }
         }
         if (!done) {
-            rc = enqueue_pdhg(h, p, pl, d_tab, 0, p.maxiter, &buf, &launches);
+            rc = enqueue_pdhg(h, p, pl, d_tab, 0, main_iters, &buf, &launches, from_state);
             if (rc) return rc;
         }
         h->st.iterations = p.maxiter;
@@ -663,9 +690,9 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
         }
     } else {
         int it = 0;
-        while (it < p.maxiter) {
-            const int it1 = std::min(p.maxiter, it + p.check_every);
-            rc = enqueue_pdhg(h, p, pl, d_tab, it, it1, &buf, &launches);
+        while (it < main_iters) {
+            const int it1 = std::min(main_iters, it + p.check_every);
+            rc = enqueue_pdhg(h, p, pl, d_tab, it, it1, &buf, &launches, from_state);
             if (rc) return rc;
             it = it1;
             h->result_buf = buf;
@@ -679,7 +706,12 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             h->st.last_gap = gmax;
             if (p.gap_tol > 0.0 && gmax <= p.gap_tol) break;
         }
-        h->st.iterations = it;
+        h->st.iterations = it + ((p.order && it == main_iters) ? 1 : 0);
+    }
+    if (p.order && h->st.iterations == p.maxiter) {   // dual-first: the primal step of the last iteration
+        hipLaunchKernelGGL(pdhg_xstep_kernel, dim3(gtot), dim3(256), 0, h->stream, h->d_f, h->cur_state[buf][1], h->cur_state[buf][2],
+                           d_tab + (size_t)TAB_STRIDE * (p.maxiter - 1), h->M, h->N, h->O, total, h->cur_state[buf][0]);
+        HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -801,7 +833,7 @@ int band_alloc(bpltv_t* h) {
 }
 
 // ---- the three factorisations of the reduced adjoint system ----------------------
-enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3 };   // also bpltv_stats_t::adjoint_method
+enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3, ADJ_BAND_LU = 4, ADJ_ND = 5 };   // also bpltv_stats_t::adjoint_method
 
 // Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
 // reduction) and make sure its workspace exists.
@@ -983,6 +1015,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
     h->st.adjoint_method = (int)method;
+    h->st.hb_sync = (method == ADJ_BAND_HBM) ? (h->hb.value_sync ? 2 : 1) : 0;
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
@@ -1041,7 +1074,9 @@ int check_params(bpltv_t* h, const bpltv_params& p) {
     if (!(p.tau0 > 0.0) || !(p.sigma0 > 0.0) || !std::isfinite(p.tau0) || !std::isfinite(p.sigma0))
         return set_err(h, BPLTV_E_ARG, "tau0 and sigma0 must be positive and finite");
     if (!(p.rho >= 0.0) || !std::isfinite(p.rho)) return set_err(h, BPLTV_E_ARG, "rho must be >= 0 and finite");
-    if (p.reserved[4] < 0 || p.reserved[4] > 2) return set_err(h, BPLTV_E_ARG, "unknown adjoint factorisation %d", p.reserved[4]);
+    if (p.reserved[4] < 0 || p.reserved[4] > 3) return set_err(h, BPLTV_E_ARG, "unknown adjoint factorisation %d", p.reserved[4]);
+    if ((p.init != 0 && p.init != 1) || (p.order != 0 && p.order != 1)) return set_err(h, BPLTV_E_ARG, "params.init and params.order must be 0 or 1");
+    if (!(p.opnorm >= 0.0) || !std::isfinite(p.opnorm)) return set_err(h, BPLTV_E_ARG, "params.opnorm must be >= 0 and finite (0 = default)");
     return BPLTV_OK;
 }
 
@@ -1142,6 +1177,8 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     int rc = sr_alloc(h);
     if (rc) return rc;
     double* d_tab = nullptr;
+    if (p.init != 0 || p.order != 0)
+        return set_err(h, BPLTV_E_UNSUPPORTED, "params.init / params.order are implemented for the TV model only");
     rc = get_table(h, p, &d_tab, 18.0);   // ||G_f||^2 + ||G_b||^2 + ||G_c||^2 <= 8 + 8 + 2 (sumregs_oracle.c: SR_L)
     if (rc) return rc;
     const int M = h->M, N = h->N;
@@ -1182,7 +1219,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     bool done = false;
     if (p.use_graph && nl <= 50000) {
-        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, p.rho, p.tau0, p.sigma0};
+        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, p.rho, p.tau0, p.sigma0, (const void*)d_tab};
         auto it = h->sr_graphs.find(key);
         if (it == h->sr_graphs.end()) {
             if (h->sr_graphs.size() >= 8) {
@@ -1346,12 +1383,14 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
-    h->st.adjoint_method = (int)ADJ_BAND_HBM;
+    h->st.adjoint_method = lu ? (int)ADJ_BAND_LU : (int)ADJ_BAND_HBM;
+    h->st.hb_sync = lu ? 0 : (h->hb_sr.value_sync ? 2 : 1);
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
-            return set_err(h, BPLTV_E_NUMERIC, "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d", fail[k] - 1, k);
+            return set_err(h, BPLTV_E_NUMERIC, lu ? "sum-of-regularisers adjoint, banded LU without pivoting: zero, tiny or non-finite pivot at column %d of image %d"
+                                                  : "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d", fail[k] - 1, k);
         const double* q = &resn[4 * (size_t)k];
         const double raw = std::sqrt(q[0]) / (q[1] > 0 ? std::sqrt(q[1]) : 1.0);
         const double scl = std::sqrt(q[2]) / (q[3] > 0 ? std::sqrt(q[3]) : 1.0);
@@ -1504,6 +1543,8 @@ int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nsh
             ms->comm.clear();
             return set_err(h, BPLTV_E_HIP, "ncclCommInitAll over %d devices failed: %s", n, ncclGetErrorString(r));
         }
+        int cnt = 0;   // what RCCL itself reports for the communicator (bench.py / the tests print it)
+        if (ncclCommCount(ms->comm[0], &cnt) == ncclSuccess) h->st.nccl_ranks = cnt;
     }
     return BPLTV_OK;
 }
@@ -1527,7 +1568,7 @@ int multi_stats(bpltv_t* h) {   // aggregate the shards' statistics into h->st
         a.adjoint_attempts = std::max(a.adjoint_attempts, b.adjoint_attempts);
         a.iterations = std::max(a.iterations, b.iterations);
     }
-    a.ngpus = h->st.ngpus; a.shards = h->st.shards;
+    a.ngpus = h->st.ngpus; a.shards = h->st.shards; a.nccl_ranks = h->st.nccl_ranks;
     a.collective = h->st.collective; a.collective_ms = h->st.collective_ms;
     a.total_ms = h->st.total_ms;
     h->st = a;

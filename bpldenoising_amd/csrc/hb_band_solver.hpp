@@ -111,8 +111,13 @@ struct HbBandSolver {
         }                                                                                         \
     } while (0)
 
-    // returns 0, 2 (HIP error) or 5 (out of memory); `err` holds the message
+    // returns 0, 2 (HIP error) or 5 (out of memory); `err` holds the message.  Nothing stays allocated on failure.
     int alloc(int bw_, int n_, int O_, hipStream_t st, bool allow_twist = true) {
+        const int rc = alloc_impl(bw_, n_, O_, st, allow_twist);
+        if (rc) release();
+        return rc;
+    }
+    int alloc_impl(int bw_, int n_, int O_, hipStream_t st, bool allow_twist) {
         bw = bw_; n = n_; O = O_; stream = st;
         Shape s = allow_twist ? shape(bw, n) : Shape{1, 0, 0, n_};
         twisted = s.sides == 2; sides = s.sides; m = s.m; nm = s.nm; np = s.np;
@@ -137,6 +142,10 @@ struct HbBandSolver {
                         break;
                     }
                 }
+            if (e4 && e4[0] == 'v' && !value_sync) {   // asked for explicitly: no silent fallback to events
+                err = "BPLTV_HB_SYNC=value: stream memory operations (hipStreamWaitValue32 on signal memory) are not available on this device";
+                return 2;
+            }
         }
         HBCHK(hipMalloc((void**)&band, (size_t)O * sides * np * W * sizeof(double)));
         HBCHK(hipMalloc((void**)&buf, bufs_doubles(O * sides, twisted ? m : n, bw) * sizeof(double)));

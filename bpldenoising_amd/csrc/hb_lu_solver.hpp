@@ -47,6 +47,7 @@ __global__ __launch_bounds__(LU_T) void hb_getri_kernel(const double* __restrict
                                                         int n, int k0, int npanel, double* __restrict__ Ainv,
                                                         double* __restrict__ AinvT, int* __restrict__ fail) {
     extern __shared__ double S[];
+    __shared__ double d0[HB2_NB];   // |diagonal| of the block as loaded: the scale a pivot is compared with
     constexpr int MP = HB2_NB, ld = MP + 1;
     const int W = bw + 1;
     const int img = blockIdx.x, tid = threadIdx.x;
@@ -60,13 +61,16 @@ __global__ __launch_bounds__(LU_T) void hb_getri_kernel(const double* __restrict
             x = (d <= bw) ? (r >= c ? BL[(size_t)(k0 + c) * W + d] : BU[(size_t)(k0 + r) * W + d]) : 0.0;
         }
         S[r + ld * c] = x;
+        if (r == c) d0[r] = fabs(x);
     }
     __syncthreads();
     const int j = tid & (MP - 1), i0 = tid >> 7;   // thread: column j, rows i0 + 8 m
-    bool bad = false;
+    int badk = -1;
     for (int k = 0; k < MP; ++k) {
         const double piv = S[k + ld * k];
-        if (!(piv != 0.0) || piv != piv) bad = true;
+        // no pivoting: a pivot that is zero, not finite, or has lost every digit against the diagonal entry it
+        // started from (|piv| < eps |a_kk|) means the elimination has broken down at this column
+        if (badk < 0 && !(fabs(piv) > 2.220446049250313e-16 * d0[k] && fabs(piv) < 1.7e308)) badk = k;
         const double pinv = 1.0 / piv;
         const double rk = (j == k) ? pinv : S[k + ld * j] * pinv;
         double nv[16];
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(LU_T) void hb_getri_kernel(const double* __restrict
         for (int mq = 0; mq < 16; ++mq) S[i0 + 8 * mq + ld * j] = nv[mq];
         __syncthreads();
     }
-    if (bad && tid == 0 && fail[img] == 0) fail[img] = k0 + 1;
+    if (badk >= 0 && tid == 0 && fail[img] == 0) fail[img] = k0 + badk + 1;
     double* Ai = Ainv + ((size_t)img * npanel + k0 / MP) * MP * MP;
     double* AiT = AinvT + ((size_t)img * npanel + k0 / MP) * MP * MP;
     for (int e = tid; e < MP * MP; e += LU_T) {

@@ -378,6 +378,72 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Non-default starts of the recurrence (bpltv_params.init / order: the choices the reference does not pin,
+// DESIGN.md section 2.3; checker: bplo_pdhg_opts of the oracle).  The hot kernel above is not touched: a
+// dual-first run is   y <- dual step from xbar0 = x0 (this kernel)  ->  pdhg_tile_kernel for maxiter - 1
+// iterations on a step table whose row k carries sigma_{k+1}  ->  the last primal step (pdhg_xstep_kernel).
+// ------------------------------------------------------------------------------------------
+// x0 = f (init 0) or 0 (init 1); y0 = 0, or -- dual_first -- the dual step of iteration 0 from xbar0 = x0:
+// the arithmetic of pdhg_y_pass (oracle) with y = 0.  One thread per pixel of every solve image.
+__global__ __launch_bounds__(256) void pdhg_init_kernel(const double* __restrict__ f, const double* __restrict__ alpha,
+                                                        int am, int an, int M, int N, int Odata, int astride, size_t total,
+                                                        int init, int dual_first, double sigma, double rho,
+                                                        double* __restrict__ x, double* __restrict__ y1,
+                                                        double* __restrict__ y2) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t npx = (size_t)M * N;
+    const int img = (int)(e / npx);
+    const int q = (int)(e - (size_t)img * npx);
+    const int i = q % M, j = q / M;
+    const double* __restrict__ fk = f + (size_t)(img % Odata) * npx;
+    const double x0 = init ? 0.0 : fk[q];
+    double y1n = 0.0, y2n = 0.0;
+    if (dual_first) {
+        const double xi1 = (i < M - 1) ? (init ? 0.0 : fk[q + 1]) : x0;
+        const double xj1 = (j < N - 1) ? (init ? 0.0 : fk[q + M]) : x0;
+        const double d1 = (i < M - 1) ? xi1 - x0 : 0.0;
+        const double d2 = (j < N - 1) ? xj1 - x0 : 0.0;
+        const double a = alpha_at(alpha + (size_t)(img / Odata) * astride, am, an, M, N, i, j);
+        y1n = __builtin_fma(sigma, d1, 0.0);
+        y2n = __builtin_fma(sigma, d2, 0.0);
+        if (rho != 0.0) {
+            const double den = 1.0 + sigma * rho / a;
+            y1n = y1n / den;
+            y2n = y2n / den;
+        }
+        const double n2 = __builtin_fma(y2n, y2n, y1n * y1n);
+        if (n2 > a * a) {
+            const double v = a * rsqrt_nr(n2);
+            y1n = y1n * v;
+            y2n = y2n * v;
+        }
+    }
+    x[e] = x0;
+    y1[e] = y1n;
+    y2[e] = y2n;
+}
+
+// The closing primal step of a dual-first run (pdhg_x_pass of the oracle; xbar is not needed any more).
+// In place: a thread reads neighbouring duals and its own x only.
+__global__ __launch_bounds__(256) void pdhg_xstep_kernel(const double* __restrict__ f, const double* __restrict__ y1,
+                                                         const double* __restrict__ y2, const double* __restrict__ tabrow,
+                                                         int M, int N, int Odata, size_t total, double* __restrict__ x) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t npx = (size_t)M * N;
+    const int img = (int)(e / npx);
+    const int q = (int)(e - (size_t)img * npx);
+    const int i = q % M, j = q / M;
+    const double tau = tabrow[0], inv1ptau = tabrow[3];
+    const double y1m = (i > 0) ? y1[e - 1] : 0.0;
+    const double y2m = (j > 0) ? y2[e - M] : 0.0;
+    const double div = (y1m - y1[e]) + (y2m - y2[e]);
+    const double t = div - f[(size_t)(img % Odata) * npx + q];
+    x[e] = __builtin_fma(-tau, t, x[e]) * inv1ptau;
+}
+
+// ------------------------------------------------------------------------------------------
 // Reductions: wave64 shuffle -> LDS -> one partial per block; a second single-block kernel sums
 // the partials in a fixed order (bitwise reproducible, no atomics).
 // ------------------------------------------------------------------------------------------

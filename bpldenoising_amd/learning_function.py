@@ -59,6 +59,7 @@ _PARAM_ALIASES = {
     "accel": "accel", "maxiter": "maxiter", "Δt": "delta_t", "delta_t": "delta_t",
     "check_every": "check_every", "gap_tol": "gap_tol", "tile_iters": "tile_iters",
     "use_graph": "use_graph", "kappa_cap": "kappa_cap", "refine": "refine", "deterministic": "deterministic",
+    "init": "init", "order": "order", "opnorm": "opnorm",
 }
 _IGNORED = {"verbose_iter", "save_results", "save_iterations", "op", "α", "alpha"}
 # ^ reference keys with no numerical meaning on this path (TVLearningFunctionVec.jl:39-42)
@@ -128,7 +129,7 @@ class TVSolver:
         if serialize is not None:
             p.reserved[2] = int(bool(serialize))  # replay launch chains one after the other (timing aid)
         if adjm is not None:
-            p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2}.get(adjm, adjm)  # adjoint factorisation
+            p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2, "nd": 3}.get(adjm, adjm)  # adjoint factorisation
         return p
 
     def _batch(self, a, what):

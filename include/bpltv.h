@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BPLTV_VERSION 2
+#define BPLTV_VERSION 3
 
 enum {
     BPLTV_OK = 0,
@@ -82,7 +82,17 @@ typedef struct bpltv_params {
                             [3] must be 0 (BPLTV_E_ARG otherwise); timing-experiment switches exist only in
                                 tools/ builds compiled with -DBPLTV_EXPERIMENTS
                             [4] adjoint factorisation: 0 automatic, 1 banded Cholesky, 2 block cyclic reduction
-                                (M <= 128, N >= 2; BPLTV_E_UNSUPPORTED otherwise)                   */
+                                (M <= 128, N >= 2; BPLTV_E_UNSUPPORTED otherwise), 3 nested-dissection
+                                (multifrontal) Cholesky                                             */
+    /* The three choices of the PDHG recurrence that the reference does not pin (its loop, op_denoise_pdps, lives
+     * in the absent package VariationalImaging: src/TVLearningFunctionVec.jl:33-43,52).  0
+     * everywhere = the restatement every parity claim refers to.  A user who has VariationalImaging on disk and
+     * finds it differs aligns the library with these fields instead of rebuilding it.  TV model, dtype 64. */
+    int init;            /* 0: x0 = f (default); 1: x0 = 0                                         */
+    int order;           /* 0: primal step first (default); 1: dual step first (y from xbar of the previous
+                            iteration, then x, then the over-relaxation)                           */
+    double opnorm;       /* operator-norm estimate L dividing tau0 and sigma0; 0 = sqrt(8) (sum of
+                            regularisers: sqrt(18)), e.g. 2*sqrt(2)*(1 - 1/n) for a tighter bound   */
 } bpltv_params;
 
 typedef struct bpltv_stats {
@@ -112,14 +122,21 @@ typedef struct bpltv_stats {
     int adjoint_attempts;      /* factorisations tried by the last gradient: 1 = no breakdown, 2..3 = the
                                   weight was reduced by 1e-2 per retry after a non-positive pivot      */
     int adjoint_method;        /* 1 banded Cholesky (LDS window), 2 block cyclic reduction,
-                                  3 banded Cholesky (HBM band)                                         */
+                                  3 banded Cholesky (HBM band), 4 banded LU (sum of regularisers, row-scaled
+                                  gradient_reg system), 5 nested-dissection (multifrontal) Cholesky      */
     int reg_gradient_used;     /* 1 if the last evaluate took the gradient_reg branch             */
     int ngpus;                 /* distinct devices behind this handle (1 for bpltv_create)        */
     int shards;                /* image shards (= worker threads) behind this handle              */
     int collective;            /* last evaluate of a multi handle: 0 none (one shard), 1 ncclAllReduce,
                                   2 ncclAllGather + ordered sum, 3 host sum (repeated devices)     */
     double collective_ms;      /* host wall time of that collective (launch + completion)        */
-    int reserved[4];
+    int nccl_ranks;            /* ranks of the RCCL communicator behind a multi handle as RCCL itself reports them
+                                  (ncclCommCount); 0 = no communicator (single-device handle, repeated devices)  */
+    int hb_sync;               /* cross-stream dependencies of the HBM band pipeline used by the last gradient:
+                                  0 not used, 1 HIP events, 2 stream memory operations (hipStreamWaitValue32)    */
+    int adjoint_chunks;        /* image groups the last adjoint gradient was processed in (1 = whole batch at once;
+                                  more when the factor workspace of all images does not fit, BPLTV_ADJ_BUDGET_MB) */
+    int reserved[1];
 } bpltv_stats_t;
 
 #define BPLTV_RESIDUAL_GATE 1e-6

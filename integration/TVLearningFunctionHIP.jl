@@ -8,12 +8,19 @@ export tv_op_learning_function, denoise, sumregs_learning_function
 
 const libbpltv = "libbpltv"            # on LD_LIBRARY_PATH, or an absolute path
 
-# Devices behind the handle: 0 = every visible MI355X (bpltv_create_multi shards the images over them and
-# all-reduces [cost, grad...] with RCCL inside the library); 1 = a single GPU.  One Julia task drives all of
-# them -- the structure of src/TRBox.jl:192-273 does not change.
-const BPLTV_NGPUS = parse(Int, get(ENV, "BPLTV_NGPUS", "0"))
+# Devices behind the handle: 1 = a single GPU (default); 0 = every visible MI355X (bpltv_create_multi shards the
+# images over them and all-reduces [cost, grad...] with RCCL inside the library).  One Julia task drives all of
+# them -- the structure of src/TRBox.jl:192-273 does not change.  The default stays 1 until the n > 1 RCCL path
+# has run on a multi-GPU node (tests/test_gpu_multi.py holds the device-count-gated checks for that first run).
+const BPLTV_NGPUS = parse(Int, get(ENV, "BPLTV_NGPUS", "1"))
 # 1: totals bitwise independent of the number of GPUs (all-gather of per-image rows, added in image order)
 const BPLTV_DETERMINISTIC = parse(Int, get(ENV, "BPLTV_DETERMINISTIC", "0"))
+# The choices of the PDHG loop the reference does not pin (VariationalImaging.op_denoise_pdps is not in the repo):
+# set these if your installed VariationalImaging starts from x0 = 0, takes the dual step first, or estimates the
+# operator norm differently (include/bpltv.h: bpltv_params.init / order / opnorm; 0 = the restatement).
+const BPLTV_INIT = parse(Int, get(ENV, "BPLTV_INIT", "0"))
+const BPLTV_ORDER = parse(Int, get(ENV, "BPLTV_ORDER", "0"))
+const BPLTV_OPNORM = parse(Float64, get(ENV, "BPLTV_OPNORM", "0"))
 
 # struct bpltv_params (include/bpltv.h) -- field order and types must match
 struct BpltvParams
@@ -27,6 +34,9 @@ struct BpltvParams
     refine::Cint
     deterministic::Cint
     reserved::NTuple{5,Cint}
+    init::Cint            # 0: x0 = f; 1: x0 = 0                  (unpinned choices of op_denoise_pdps,
+    order::Cint           # 0: primal step first; 1: dual first    DESIGN.md 2.3; 0 = the restatement)
+    opnorm::Cdouble       # operator-norm estimate L; 0 = sqrt(8)
 end
 
 mutable struct BpltvHandle
@@ -65,7 +75,7 @@ function default_params(; kwargs...)
     return BpltvParams(get_(:ρ, p.rho), get_(:τ₀, p.tau0), get_(:σ₀, p.sigma0),
                        get_(:accel, p.accel != 0) ? 1 : 0, get_(:maxiter, p.maxiter),
                        get_(:Δt, p.delta_t), p.check_every, p.gap_tol, p.tile_iters, p.use_graph,
-                       p.kappa_cap, p.refine, BPLTV_DETERMINISTIC, p.reserved)
+                       p.kappa_cap, p.refine, BPLTV_DETERMINISTIC, p.reserved, BPLTV_INIT, BPLTV_ORDER, BPLTV_OPNORM)
 end
 
 const _handle = Ref{Union{Nothing,BpltvHandle}}(nothing)
@@ -132,7 +142,7 @@ function sumregs_learning_function(x::Union{AbstractVector{Float64},AbstractArra
     ccall((:bpltv_sumregs_default_params, libbpltv), Cint, (Ref{BpltvParams},), r)
     d = r[]
     p = Ref(BpltvParams(d.rho, d.tau0, d.sigma0, d.accel, d.maxiter, Δt, d.check_every, d.gap_tol, d.tile_iters,
-                        d.use_graph, d.kappa_cap, d.refine, BPLTV_DETERMINISTIC, d.reserved))
+                        d.use_graph, d.kappa_cap, d.refine, BPLTV_DETERMINISTIC, d.reserved, BPLTV_INIT, BPLTV_ORDER, BPLTV_OPNORM))
     GC.@preserve a u grad bpltv_check(h, ccall((:bpltv_sumregs_evaluate, libbpltv), Cint,
         (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ref{BpltvParams}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}),
         h.ptr, a, am, an, Δ, p, u, cost, grad))

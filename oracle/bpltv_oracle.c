@@ -380,6 +380,42 @@ BPLO_API int bplo_pdhg(int M, int N, int O, const double *f, const double *alpha
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The recurrence in "spec v2" arithmetic (pdhg_x_pass / pdhg_y_pass, bit for bit) with the three run-time choices
+ * of include/bpltv.h: bpltv_params.init / order / opnorm -- the degrees of freedom the reference leaves open
+ * because op_denoise_pdps (/root/reference/src/TVLearningFunctionVec.jl:52,67) is not in its repository.
+ *   init  0: x0 = f, 1: x0 = 0;   order 0: primal step first, 1: dual step first (y from xbar of the previous
+ *   iteration -- xbar0 = x0 --, then x, then the over-relaxation);   L: operator-norm estimate (> 0).
+ * init = order = 0, L = sqrt(8) is bplo_pdhg.  Checker of the library's non-default starts (tests/test_gpu_pdhg.py).
+ * ---------------------------------------------------------------------------------------- */
+BPLO_API int bplo_pdhg_opts(int M, int N, int O, const double *f, const double *alpha, int am, int an, double rho,
+                            double tau0, double sigma0, int accel, int maxiter, int init, int order, double L,
+                            double *x_out, double *y1_out, double *y2_out)
+{
+    if (M < 1 || N < 1 || O < 0 || maxiter < 0 || !(L > 0.0)) return 1;
+    const size_t n = (size_t)M * N;
+    double *tab = (double *)malloc(sizeof(double) * 5 * (size_t)(maxiter > 0 ? maxiter : 1));
+    double *xb = (double *)malloc(n * sizeof(double));
+    double *t1 = (double *)malloc(n * sizeof(double)), *t2 = (double *)malloc(n * sizeof(double));
+    if (!tab || !xb || !t1 || !t2) { free(tab); free(xb); free(t1); free(t2); return 2; }
+    bplo_step_table_L(maxiter, tau0, sigma0, accel, L, tab);
+    for (int k = 0; k < O; ++k) {
+        const double *fk = f + n * k;
+        double *x = x_out + n * k;
+        double *y1 = y1_out ? y1_out + n * k : t1, *y2 = y2_out ? y2_out + n * k : t2;
+        for (size_t e = 0; e < n; ++e) { x[e] = init ? 0.0 : fk[e]; xb[e] = x[e]; y1[e] = 0.0; y2[e] = 0.0; }
+        for (int it = 0; it < maxiter; ++it) {
+            const double tau = tab[5 * it], sigma = tab[5 * it + 1], omega = tab[5 * it + 2];
+            const double inv1ptau = tab[5 * it + 3], opw = tab[5 * it + 4];
+            if (order) pdhg_y_pass(M, N, 0, N, alpha, am, an, xb, sigma, rho, y1, y2);
+            pdhg_x_pass(M, 0, N, fk, y1, y2, tau, omega, inv1ptau, opw, x, xb);
+            if (!order) pdhg_y_pass(M, N, 0, N, alpha, am, an, xb, sigma, rho, y1, y2);
+        }
+    }
+    free(tab); free(xb); free(t1); free(t2);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * The same ROF solver with each UNPINNED choice of the restatement flipped (tools/unpinned_study.py,
  * tests/test_unpinned.py).  The loop of op_denoise_pdps lives in an absent package, so these are the degrees
  * of freedom a faithful restatement has; the study bounds what they can change after the reference's 5000

@@ -153,6 +153,27 @@ def pdhg_variant(f, alpha, maxiter=5000, flags=0, L=None, tau0=5.0, sigma0=0.99 
     return x.reshape(f.shape)
 
 
+def pdhg_opts(f, alpha, maxiter=5000, init=0, order=0, L=None, rho=0.0, tau0=5.0, sigma0=0.99 / 5, accel=True,
+              return_dual=False):
+    """bplo_pdhg_opts: the oracle's own arithmetic with the run-time choices of bpltv_params.init / order / opnorm."""
+    f = _c(f)
+    f3 = f.reshape((-1,) + f.shape[-2:])
+    O, N, M = f3.shape
+    a, am, an = alpha_arg(alpha)
+    x = np.empty_like(f3); y1 = np.empty_like(f3); y2 = np.empty_like(f3)
+    fn = lib().bplo_pdhg_opts
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] * 3 + [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                   C.c_int, C.c_double, _dp, _dp, _dp]
+    rc = fn(M, N, O, _p(f3), _p(a), am, an, rho, tau0, sigma0, int(accel), maxiter, int(init), int(order),
+            float(np.sqrt(8.0) if L is None else L), _p(x), _p(y1), _p(y2))
+    if rc:
+        raise RuntimeError("bplo_pdhg_opts rc=%d" % rc)
+    if return_dual:
+        return x.reshape(f.shape), y1.reshape(f.shape), y2.reshape(f.shape)
+    return x.reshape(f.shape)
+
+
 _native = None
 _SO_NATIVE = os.path.join(_HERE, "libbpltv_oracle_native.so")
 

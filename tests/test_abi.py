@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libbpltv.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names          # the binding covers exactly the header
-    assert lib.bpltv_version() == 2
+    assert lib.bpltv_version() == 3
 
 
 def test_default_params_match_reference():
@@ -33,6 +33,7 @@ def test_default_params_match_reference():
     assert (p.rho, p.tau0, p.accel, p.maxiter, p.delta_t) == (0.0, 5.0, 1, 5000, 1e-6)
     assert p.sigma0 == 0.99 / 5
     assert p.gap_tol == 0.0 and p.check_every == 0      # fixed iteration count, as the reference
+    assert (p.init, p.order, p.opnorm) == (0, 0, 0.0)    # the restatement
     assert lib.bpltv_default_params(None) != 0
 
 

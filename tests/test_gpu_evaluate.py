@@ -522,9 +522,12 @@ def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
         monkeypatch.setenv("BPLTV_HB_SINGLE_STREAM", "1" if mode == "single-stream" else "0")
         s = gpu_solver_cls(M, N, O)
         s.set_data(ub, f)
-        _, _, g = s.evaluate(amap, 0.1, maxiter=300)
+        _, _, g = s.evaluate(amap, 0.1, maxiter=300, adjoint_method="band")
         st = s.stats()
         assert st["adjoint_method"] == "band-hbm" and st["adjoint_residual"] <= 1e-8
+        # the mode that ran, as the library reports it: BPLTV_HB_SYNC=value fails hard when stream memory operations
+        # are unavailable, so the 'value' leg cannot pass as a second 'event' leg
+        assert st["hb_sync"] == ("value" if mode == "value" else "event"), st["hb_sync"]
         res.append(g)
         s.close()
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])

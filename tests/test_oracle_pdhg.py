@@ -76,3 +76,19 @@ def test_f32_twin_tracks_the_f64_recurrence(oracle):
     assert np.abs(oracle.pdhg_f32(f, 0.0, maxiter=20) - f).max() < 1e-6    # (x + tau f) / (1 + tau) in float
     amap = 0.05 + 0.1 * rng.random((24, 20))
     assert np.abs(oracle.pdhg(f, amap, maxiter=200) - oracle.pdhg_f32(f, amap, maxiter=200)).max() < 1e-5
+
+
+def test_pdhg_opts_is_the_oracle_recurrence_with_the_unpinned_choices(oracle):
+    """bplo_pdhg_opts (checker of bpltv_params.init / order / opnorm): defaults == bplo_pdhg bit for bit; each choice
+    flipped agrees with the unfused study code bplo_pdhg_variant to rounding."""
+    from conftest import synth_batch
+    ub, f = synth_batch(2, 40, 36, seed=5)
+    alpha = np.array([[0.05, 0.1], [0.2, 0.08]])
+    assert np.array_equal(oracle.pdhg_opts(f, alpha, maxiter=120), oracle.pdhg(f, alpha, maxiter=120))
+    for init, order, flags in ((1, 0, 1), (0, 1, 2), (1, 1, 3)):
+        a = oracle.pdhg_opts(f, alpha, maxiter=120, init=init, order=order)
+        b = oracle.pdhg_variant(f, alpha, maxiter=120, flags=flags)
+        assert np.abs(a - b).max() < 1e-12
+        assert np.abs(a - oracle.pdhg(f, alpha, maxiter=120)).max() > 1e-9      # and it is a different sequence
+    L = 2 * np.sqrt(2) * (1 - 1 / 36)
+    assert np.abs(oracle.pdhg_opts(f, alpha, maxiter=120, L=L) - oracle.pdhg_variant(f, alpha, maxiter=120, L=L)).max() < 1e-12
