@@ -1,0 +1,624 @@
+// nd_kernels.hpp -- numeric kernels of the nested-dissection (multifrontal) Cholesky, gfx950.
+//
+// Replaces the sparse direct solve behind Julia's `\` at /root/reference/src/TVLearningFunctionVec.jl:131,248 (and
+// /root/reference/src/SumRegsLearningFunction.jl:324,394) for images too wide for block cyclic reduction: the tree
+// of csrc/nd_symbolic.hpp turns the stencil matrix into dense fronts, and every level of the tree is eliminated by a
+// handful of launches over (front, image).  Front F of a node with p pivots and b boundary pixels (f = p + b):
+//     F = [ F11 F21^T ]      F11 = L11 L11^T,  L21 = F21 L11^-T,  U = F22 - L21 L21^T  (update matrix, to the parent)
+//         [ F21 F22   ]
+// Storage (per image): the factor columns of the node, f x p with leading dimension f -- rows [0, p) end up holding
+// W = L11^-1 (lower triangular; the substitutions only ever apply L11^-1, never L11), rows [p, f) hold L21 -- and
+// the update matrix U, b x b, in the workspace of the node's level parity (the parent reads it one level later).
+// Only lower triangles are assembled and read.
+//
+// Two regimes, chosen per level:
+//   small  (front padded to 16 fits 128 x 128): one workgroup per (front, image) assembles the front in LDS (matrix
+//          entries + the children's update matrices through cmap), factors its pivot block columns (wave 0 in
+//          registers, bcr_panel_factor), applies them to the rest on the f64 MFMA and writes W, L21, U.
+//   large  the front stays in HBM/L2: scatter kernels assemble it, then per 128-column pivot panel
+//          nd_potrf_kernel (Cholesky + inverse of the diagonal block in LDS, bcr_potrf_lds_body) ->
+//          nd_trsm_kernel (rows below: x L11^-T, MFMA tiles, in place) -> nd_syrk_kernel (remaining pivot columns),
+//          and one nd_schur_kernel for U with the whole depth p (64 x 64 MFMA tiles).
+// Substitutions in gather form (no atomics, fixed summation order, bitwise reproducible): forward, level by level
+// from the leaves, a front subtracts its children's update vectors, applies W and hands L21 y to its parent;
+// backward from the root, x_p = W^T (y_p - L21^T x_b).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "adjoint_hbm_kernels.hpp"
+
+namespace bpltv {
+
+struct NdNodeDev {
+    int p, b;
+    int piv_off, cmap_off;
+    int orig_off, orig_cnt;
+    int child0, child1;
+    long long fac_off, u_off, uv_off;
+};
+
+struct NdArgs {
+    const NdNodeDev* nodes;
+    const int* pix;
+    const int* cmap;
+    const int4* orig;          // (r, c, plane, pixel)
+    const double* planes;      // assembled diagonals: planes[plane * tot + img * n + pixel]
+    size_t tot;
+    int n;                     // pixels per image
+    double* fac;               // [nimg][fac_stride]
+    long long fac_stride;
+    double* ws_mine;           // update matrices of this level   [nimg][ws_mine_stride]
+    const double* ws_child;    // update matrices of the children [nimg][ws_child_stride]
+    long long ws_mine_stride, ws_child_stride;
+    int node0;                 // first node of the batch: blockIdx.y = node - node0
+    int* fail;                 // [nimg]: node + 1 of the first non-positive pivot
+};
+
+__host__ __device__ inline int nd_up16(int x) { return (x + 15) & ~15; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// small regime
+// ------------------------------------------------------------------------------------------------------------------
+// Partial Cholesky in LDS: the first Pp block columns (16 columns each) of the MP x MP matrix S (leading dimension
+// ld = MP + 1, lower triangle) are factored, the inverse of the Pp x Pp pivot tile block is formed, and the
+// remaining tiles receive -L21 L21^T.  Layout on exit as bcr_potrf_lds_body's: strictly lower tiles hold L, the
+// pivot block's diagonal and upper tiles hold W = L11^-1 (tile (p, q), q <= p, at tile position (q, p)).
+// dinv: MP doubles of scratch.  Returns true (wave 0) on a non-positive pivot.  NT threads.
+template <int NT>
+__device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP, int Pp, double* __restrict__ dinv) {
+    const int ld = MP + 1, P = MP >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    constexpr int NW = NT / 64;
+    bool bad = false;
+    for (int pc = 0; pc < Pp; ++pc) {
+        if (pc > 0) {   // left-looking: block column pc receives the block columns before it
+            for (int i = pc + wave; i < P; i += NW) {
+                bcr_d4 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * pc + lr)];
+                for (int q = 0; q < pc; ++q) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
+                        const double b = S[(16 * pc + lr) + ld * (16 * q + 4 * kk + lk)];
+                        acc = bcr_mfma(-a, b, acc);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * pc + lr)] = acc[g];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            if (MP - 16 * pc > 64) bad |= bcr_panel_factor<true>(S, ld, MP, pc, lane, dinv);
+            else bad |= bcr_panel_factor<false>(S, ld, MP, pc, lane, dinv);
+        }
+        __syncthreads();
+    }
+    // trailing tiles (i, j), Pp <= j <= i: -= sum_q L(i, q) L(j, q)^T -- before the inverse overwrites nothing they
+    // read (they read strictly-lower tiles below the pivot block only)
+    {
+        const int m = P - Pp;
+        for (int t = wave; t < m * (m + 1) / 2; t += NW) {
+            int a = 0, c = t;
+            while (c > a) { c -= a + 1; ++a; }
+            const int i = Pp + a, j = Pp + c;
+            bcr_d4 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)];
+            for (int q = 0; q < Pp; ++q) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double x = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
+                    const double y = S[(16 * j + lr) + ld * (16 * q + 4 * kk + lk)];
+                    acc = bcr_mfma(-x, y, acc);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)] = acc[g];
+        }
+    }
+    // W = L11^-1: diagonal tiles, then tile row by tile row (row p needs the rows above it)
+    for (int t = wave; t < Pp; t += NW) bcr_tile_inverse(S + 16 * t + ld * (16 * t), ld, lane, dinv + 16 * t);
+    __syncthreads();
+    for (int p = 1; p < Pp; ++p) {
+        for (int q = wave; q < p; q += NW) bcr_winv_tile(S, ld, p, q, lr, lk);
+        __syncthreads();
+    }
+    return bad;
+}
+
+constexpr int NDS_T = 256;
+inline size_t nd_small_lds(int MP) { return sizeof(double) * ((size_t)(MP + 1) * MP + MP); }
+
+// One workgroup per (front, image).  grid (nodes of the batch, nimg), block NDS_T, dynamic LDS nd_small_lds(MPmax).
+__global__ __launch_bounds__(NDS_T) void nd_front_small_kernel(NdArgs A) {
+    extern __shared__ double S[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, p16 = nd_up16(p), sh = p16 - p;
+    const int MP = nd_up16(p16 + b), ld = MP + 1, Pp = p16 >> 4;
+    double* dinv = S + (size_t)ld * MP;
+    for (int e = tid; e < ld * MP + MP; e += NDS_T) S[e] = 0.0;
+    __syncthreads();
+    for (int k = p + tid; k < p16; k += NDS_T) S[k + ld * k] = 1.0;   // identity padding of the pivot block
+    // matrix entries of this front (unique targets)
+    {
+        const double* pl = A.planes + (size_t)img * A.n;
+        for (int e = tid; e < v.orig_cnt; e += NDS_T) {
+            const int4 o = A.orig[v.orig_off + e];
+            const int r = o.x < p ? o.x : o.x + sh, c = o.y;   // c is a pivot
+            S[r + ld * c] += pl[(size_t)o.z * A.tot + o.w];
+        }
+    }
+    __syncthreads();
+    // the children's update matrices, one child after the other (a child's entries hit distinct targets)
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn < 0) continue;
+        const NdNodeDev ch = A.nodes[cn];
+        const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
+        const int* cm = A.cmap + ch.cmap_off;
+        const int bc = ch.b;
+        for (int e = tid; e < bc * bc; e += NDS_T) {
+            const int i = e % bc, j = e / bc;
+            if (i < j) continue;
+            int R = cm[i], C = cm[j];
+            R = R < p ? R : R + sh;
+            C = C < p ? C : C + sh;
+            S[R + ld * C] += Uc[e];
+        }
+        __syncthreads();
+    }
+    const bool bad = nd_partial_potrf<NDS_T>(S, MP, Pp, dinv);
+    if (bad && (tid & 63) == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    __syncthreads();
+    // factor columns: rows [0, p) = W (zeros above the diagonal), rows [p, f) = L21
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    for (int e = tid; e < f * p; e += NDS_T) {
+        const int r = e % f, c = e / f;
+        double x;
+        if (r < p) x = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
+        else x = S[(r + sh) + ld * c];
+        fc[e] = x;
+    }
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    for (int e = tid; e < b * b; e += NDS_T) {
+        const int i = e % b, j = e / b;
+        if (i >= j) U[e] = S[(p16 + i) + ld * (p16 + j)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// large regime: the front lives in HBM -- factor columns (f x p) and the update-matrix slot (b x b)
+// ------------------------------------------------------------------------------------------------------------------
+// zero the factor columns and the update-matrix slots of a level.  grid (blocks, nimg).
+__global__ __launch_bounds__(256) void nd_zero_kernel(double* __restrict__ fac, long long fac_stride, long long fac0, long long fac_len,
+                                                      double* __restrict__ ws, long long ws_stride, long long ws_len) {
+    const int img = blockIdx.y;
+    double* a = fac + (size_t)img * fac_stride + fac0;
+    double* w = ws + (size_t)img * ws_stride;
+    const long long tot = fac_len + ws_len;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        if (e < fac_len) a[e] = 0.0;
+        else w[e - fac_len] = 0.0;
+    }
+}
+
+// matrix entries: every target lies in the factor columns (the column index is a pivot).  grid (nodes, nimg).
+__global__ __launch_bounds__(256) void nd_orig_kernel(NdArgs A) {
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y;
+    const NdNodeDev v = A.nodes[node];
+    const int f = v.p + v.b;
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* pl = A.planes + (size_t)img * A.n;
+    for (int e = threadIdx.x; e < v.orig_cnt; e += 256) {
+        const int4 o = A.orig[v.orig_off + e];
+        fc[o.x + (size_t)f * o.y] += pl[(size_t)o.z * A.tot + o.w];
+    }
+}
+
+// extend-add of child `ci` of every front of the level.  grid (blocks, nodes, nimg), block 256.
+__global__ __launch_bounds__(256) void nd_extadd_kernel(NdArgs A, int ci) {
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z;
+    const NdNodeDev v = A.nodes[node];
+    const int cn = ci ? v.child1 : v.child0;
+    if (cn < 0) return;
+    const NdNodeDev ch = A.nodes[cn];
+    const int p = v.p, b = v.b, f = p + b, bc = ch.b;
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
+    const int* cm = A.cmap + ch.cmap_off;
+    // column j of the child by one thread row each: consecutive threads read consecutive rows
+    const long long cnt = (long long)bc * bc;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (long long)gridDim.x * 256) {
+        const int j = (int)(e / bc), i = (int)(e - (long long)j * bc);
+        if (i < j) continue;
+        const int R = cm[i], C = cm[j];
+        const double x = Uc[e];
+        if (C < p) fc[R + (size_t)f * C] += x;
+        else U[(R - p) + (size_t)b * (C - p)] += x;
+    }
+}
+
+// Cholesky + inverse of the diagonal block of pivot panel k (columns [128 k, 128 k + nb)) in LDS; the block is
+// replaced by W = L^-1 (zeros above the diagonal).  grid (nodes, nimg), block BCR_PT, LDS bcr_potrf_lds(128).
+__global__ __launch_bounds__(BCR_PT) void nd_potrf_kernel(NdArgs A, int k) {
+    extern __shared__ double S[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, f = p + v.b, c0 = HB2_NB * k;
+    if (c0 >= p) return;
+    const int nb = min(HB2_NB, p - c0), MP = nd_up16(nb), ld = MP + 1;
+    double* blk = A.fac + (size_t)img * A.fac_stride + v.fac_off + c0 + (size_t)f * c0;
+    for (int e = tid; e < MP * MP; e += BCR_PT) {
+        const int r = e % MP, c = e / MP;
+        double x = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c < nb) x = (r >= c) ? blk[r + (size_t)f * c] : 0.0;
+        S[r + ld * c] = x;
+    }
+    __syncthreads();
+    const bool bad = bcr_potrf_lds_body(S, MP);
+    if (bad && (tid & 63) == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    for (int e = tid; e < nb * nb; e += BCR_PT) {
+        const int r = e % nb, c = e / nb;
+        blk[r + (size_t)f * c] = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
+    }
+}
+
+// Rows below the diagonal block of panel k: L(r, c) = sum_kk A(r, kk) W(c, kk), in place.  One workgroup owns 64 rows
+// and computes both 64-column halves before it writes (its rows are read by nobody else).
+// grid (row tiles, nodes, nimg), block BG_T.
+__global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
+    __shared__ double lds[BG_LDS];
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, f = p + v.b, c0 = HB2_NB * k;
+    if (c0 >= p) return;
+    const int nb = min(HB2_NB, p - c0);
+    const int R0 = c0 + nb + 64 * (int)blockIdx.x;
+    if (R0 >= f) return;
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* Ar = fc + R0 + (size_t)f * c0;           // A(R0 + r, c0 + kk) at Ar[r + f kk]
+    const double* Wb = fc + c0 + (size_t)f * c0;           // W(c, kk) at Wb[c + f kk]
+    const int rmax = f - R0;
+    double* As = lds;
+    double* Bs = lds + BG_KC * BG_LD;
+    BgAcc acc[2];
+    const int nhalf = nb > 64 ? 2 : 1;
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[h].c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+        if (h >= nhalf) continue;
+        const int cc0 = 64 * h;
+        const int kend = min(nb, cc0 + 64);                 // W(c, kk) = 0 for kk > c
+        const int nchunk = (kend + BG_KC - 1) / BG_KC;
+        double va[8], vb[8];
+        hb2_fetch_dense(Ar, f, rmax, kend, 0, 0, tid, va);
+        hb2_fetch_dense(Wb, f, nb, kend, cc0, 0, tid, vb);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            __syncthreads();
+            bg_stage<true>(As, tid, va);
+            bg_stage<true>(Bs, tid, vb);
+            __syncthreads();
+            if (ch + 1 < nchunk) {
+                hb2_fetch_dense(Ar, f, rmax, kend, 0, (ch + 1) * BG_KC, tid, va);
+                hb2_fetch_dense(Wb, f, nb, kend, cc0, (ch + 1) * BG_KC, tid, vb);
+            }
+            hb2_mma_chunk(As, Bs, acc[h]);
+        }
+    }
+    const int l = tid & 63, hq = tid >> 6;
+    for (int h = 0; h < nhalf; ++h) {
+        bg_to_lds(acc[h], lds);      // barriers inside: every read of A by this workgroup has completed before the first write
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int o = hq + 4 * i, c = 64 * h + o;
+            if (l < rmax && c < nb) fc[(R0 + l) + (size_t)f * (c0 + c)] = lds[o * BG_LD + l];
+        }
+    }
+}
+
+// A(R, C) -= sum_kk X(R, kk) X(C, kk) on 64 x 64 tiles of a lower-triangular region, MFMA.  Shared by the pivot-column
+// update (nd_syrk_kernel) and the update matrix (nd_schur_kernel).
+//   X: rows relative to Xb (leading dimension ldx), nrow rows, depth kdepth
+//   Out(R, C) at Ob[R + ldo C], R in [0, nrow), C in [0, ncol), R + roff >= C is written (roff: row offset of the
+//   output region against its column numbering, 0 for square regions)
+__device__ __forceinline__ void nd_tile_rank_update(const double* __restrict__ Xb, int ldx, int nrow, int kdepth, int ta, int tb,
+                                                    double* __restrict__ Ob, size_t ldo, int ncol, double* __restrict__ lds) {
+    const int tid = threadIdx.x;
+    double* As = lds;
+    double* Bs = lds + BG_KC * BG_LD;
+    BgAcc acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (kdepth + BG_KC - 1) / BG_KC;
+    double va[8], vb[8];
+    hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * ta, 0, tid, va);
+    hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * tb, 0, tid, vb);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();
+        bg_stage<true>(As, tid, va);
+        bg_stage<true>(Bs, tid, vb);
+        __syncthreads();
+        if (ch + 1 < nchunk) {
+            hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * ta, (ch + 1) * BG_KC, tid, va);
+            hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * tb, (ch + 1) * BG_KC, tid, vb);
+        }
+        hb2_mma_chunk(As, Bs, acc);
+    }
+    const int l = tid & 63, hq = tid >> 6;
+    const int R = 64 * ta + l;
+    double old[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int C = 64 * tb + hq + 4 * i;
+        old[i] = (R < nrow && C < ncol && R >= C) ? Ob[R + ldo * C] : 0.0;
+    }
+    bg_to_lds(acc, lds);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int o = hq + 4 * i, C = 64 * tb + o;
+        if (R < nrow && C < ncol && R >= C) Ob[R + ldo * C] = old[i] - lds[o * BG_LD + l];
+    }
+}
+// lower tile index t -> (ta, tb), ta >= tb
+__device__ __forceinline__ void nd_tri_decode(int t, int& ta, int& tb) {
+    int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    ta = a; tb = t - a * (a + 1) / 2;
+}
+
+// remaining pivot columns behind panel k: rows and columns counted from s0 = 128 (k + 1); columns < p.
+// grid (lower tiles of ceil((f - s0) / 64), nodes, nimg).
+__global__ __launch_bounds__(BG_T) void nd_syrk_kernel(NdArgs A, int k) {
+    __shared__ double lds[BG_LDS];
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, f = p + v.b, c0 = HB2_NB * k, s0 = c0 + HB2_NB;
+    if (s0 >= p) return;
+    int ta, tb;
+    nd_tri_decode((int)blockIdx.x, ta, tb);
+    const int nrow = f - s0, ncol = p - s0;
+    if (64 * ta >= nrow || 64 * tb >= ncol) return;
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    nd_tile_rank_update(fc + s0 + (size_t)f * c0, f, nrow, HB2_NB, ta, tb, fc + s0 + (size_t)f * s0, (size_t)f, ncol, lds);
+}
+
+// U -= L21 L21^T (depth p).  grid (lower tiles of ceil(b / 64), nodes, nimg).
+__global__ __launch_bounds__(BG_T) void nd_schur_kernel(NdArgs A) {
+    __shared__ double lds[BG_LDS];
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    int ta, tb;
+    nd_tri_decode((int)blockIdx.x, ta, tb);
+    if (64 * ta >= b) return;
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    nd_tile_rank_update(fc + p, f, b, p, ta, tb, U, (size_t)b, b, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// substitutions
+// ------------------------------------------------------------------------------------------------------------------
+struct NdSolveArgs {
+    const NdNodeDev* nodes;
+    const int* pix;
+    const int* cmap;
+    const double* fac;
+    long long fac_stride;
+    double* vec;            // [nimg][n]: right-hand side in, solution out
+    double* y;              // [nimg][n]: forward result
+    double* uv;             // [nimg][uv_stride]: update vectors
+    long long uv_stride;
+    double* acc;            // += solution when not null
+    int n, node0;
+};
+
+// Small fronts, one wave per (front, image): forward.  grid (nodes, nimg), block 64.  f <= 128.
+__global__ __launch_bounds__(64) void nd_fwd_small_kernel(NdSolveArgs A) {
+    __shared__ double w[128], yv[128];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    const int* px = A.pix + v.piv_off;
+    double* uvi = A.uv + (size_t)img * A.uv_stride;
+    for (int e = lane; e < f; e += 64) w[e] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn < 0) continue;
+        const NdNodeDev ch = A.nodes[cn];
+        const int* cm = A.cmap + ch.cmap_off;
+        const double* uc = uvi + ch.uv_off;
+        for (int e = lane; e < ch.b; e += 64) w[cm[e]] += uc[e];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const double* rhs = A.vec + (size_t)img * A.n;
+    for (int e = lane; e < p; e += 64) w[e] = rhs[px[e]] - w[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* yo = A.y + (size_t)img * A.n;
+    for (int r = lane; r < p; r += 64) {          // y = W w_p (W lower triangular, zeros stored above)
+        double acc = 0.0;
+        for (int c = 0; c <= r; ++c) acc = __builtin_fma(fc[r + (size_t)f * c], w[c], acc);
+        yv[r] = acc;
+        yo[px[r]] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < b; i += 64) {          // update vector: children's sums + L21 y
+        double acc = w[p + i];
+        for (int c = 0; c < p; ++c) acc = __builtin_fma(fc[(p + i) + (size_t)f * c], yv[c], acc);
+        uvi[v.uv_off + i] = acc;
+    }
+}
+
+// backward: x_p = W^T (y_p - L21^T x_b).  grid (nodes, nimg), block 64.
+__global__ __launch_bounds__(64) void nd_bwd_small_kernel(NdSolveArgs A) {
+    __shared__ double xb[128], z[128];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    const int* px = A.pix + v.piv_off;
+    double* x = A.vec + (size_t)img * A.n;
+    const double* yo = A.y + (size_t)img * A.n;
+    for (int i = lane; i < b; i += 64) xb[i] = x[px[p + i]];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    for (int c = lane; c < p; c += 64) {
+        double acc = yo[px[c]];
+        const double* col = fc + p + (size_t)f * c;
+        for (int i = 0; i < b; ++i) acc = __builtin_fma(-col[i], xb[i], acc);
+        z[c] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* ac = A.acc ? A.acc + (size_t)img * A.n : nullptr;
+    for (int c = lane; c < p; c += 64) {
+        double acc = 0.0;
+        const double* col = fc + (size_t)f * c;
+        for (int r = c; r < p; ++r) acc = __builtin_fma(col[r], z[r], acc);
+        x[px[c]] = acc;
+        if (ac) ac[px[c]] += acc;
+    }
+}
+
+// Large fronts, one workgroup per (front, image).  Dynamic LDS: nd_large_lds(largest front of the batch).
+constexpr int NDL_T = 1024;
+inline size_t nd_large_lds(int fmax) { return sizeof(double) * ((size_t)fmax + 9 * HB2_NB + 64); }
+
+// forward: wf = [rhs_p - s_p ; -s_b]; per pivot panel: y_k = W_kk wf_k, then wf[r] -= L(r, panel k) y_k for every row
+// below; update vector = -wf_b.  grid (nodes, nimg), block NDL_T.
+__global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A) {
+    extern __shared__ double sm[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    double* wf = sm;                // [f]
+    double* part = sm + f;          // [8][128] partial sums
+    const int* px = A.pix + v.piv_off;
+    double* uvi = A.uv + (size_t)img * A.uv_stride;
+    for (int e = tid; e < f; e += NDL_T) wf[e] = 0.0;
+    __syncthreads();
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn < 0) continue;
+        const NdNodeDev ch = A.nodes[cn];
+        const int* cm = A.cmap + ch.cmap_off;
+        const double* uc = uvi + ch.uv_off;
+        for (int e = tid; e < ch.b; e += NDL_T) wf[cm[e]] -= uc[e];
+        __syncthreads();
+    }
+    const double* rhs = A.vec + (size_t)img * A.n;
+    for (int e = tid; e < p; e += NDL_T) wf[e] += rhs[px[e]];
+    __syncthreads();
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* yo = A.y + (size_t)img * A.n;
+    const int r128 = tid & 127, g8 = tid >> 7;
+    for (int c0 = 0; c0 < p; c0 += HB2_NB) {
+        const int nb = min(HB2_NB, p - c0);
+        // y_k = W_kk wf_k: thread (row r128, column group g8)
+        {
+            double acc = 0.0;
+            if (r128 < nb) {
+                const double* Wr = fc + (c0 + r128) + (size_t)f * c0;
+                for (int c = g8; c <= r128; c += 8) acc = __builtin_fma(Wr[(size_t)f * c], wf[c0 + c], acc);
+            }
+            part[g8 * HB2_NB + r128] = acc;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+            wf[c0 + tid] = s;
+            yo[px[c0 + tid]] = s;
+        }
+        __syncthreads();
+        // rows below the diagonal block: wf[r] -= sum_c L(r, c0 + c) y[c]; 128 rows x 8 column groups per pass
+        for (int R0 = c0 + nb; R0 < f; R0 += HB2_NB) {
+            const int r = R0 + r128;
+            double acc = 0.0;
+            if (r < f) {
+                const double* Lr = fc + r + (size_t)f * c0;
+                for (int c = g8; c < nb; c += 8) acc = __builtin_fma(Lr[(size_t)f * c], wf[c0 + c], acc);
+            }
+            part[g8 * HB2_NB + r128] = acc;
+            __syncthreads();
+            if (tid < HB2_NB && R0 + tid < f) {
+                double s = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+                wf[R0 + tid] -= s;
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < b; i += NDL_T) uvi[v.uv_off + i] = -wf[p + i];
+}
+
+// backward: vf = [x_p ; x_b]; panels from the last to the first: t_c = y_c - sum_{r below the block} L(r, c) vf[r]
+// (a wave per column, lanes along the rows), x_k = W_kk^T t.  grid (nodes, nimg), block NDL_T.
+__global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A) {
+    extern __shared__ double sm[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    double* vf = sm;                // [f]
+    double* tt = sm + f;            // [128]
+    double* part = sm + f + HB2_NB; // [8][128]
+    const int* px = A.pix + v.piv_off;
+    double* x = A.vec + (size_t)img * A.n;
+    const double* yo = A.y + (size_t)img * A.n;
+    for (int i = tid; i < b; i += NDL_T) vf[p + i] = x[px[p + i]];
+    __syncthreads();
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* ac = A.acc ? A.acc + (size_t)img * A.n : nullptr;
+    const int npan = (p + HB2_NB - 1) / HB2_NB;
+    for (int k = npan - 1; k >= 0; --k) {
+        const int c0 = HB2_NB * k, nb = min(HB2_NB, p - c0), rlo = c0 + nb;
+        for (int c = wave; c < nb; c += NDL_T / 64) {
+            const double* col = fc + (size_t)f * (c0 + c);
+            double acc = 0.0;
+            for (int r = rlo + lane; r < f; r += 64) acc = __builtin_fma(col[r], vf[r], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if (lane == 0) tt[c] = yo[px[c0 + c]] - acc;
+        }
+        __syncthreads();
+        // x_k = W_kk^T t: x[c] = sum_{r >= c} W(r, c) t[r]; thread (column c = tid & 127, row group g8)
+        {
+            const int c = tid & 127, g8 = tid >> 7;
+            double acc = 0.0;
+            if (c < nb) {
+                const double* Wc = fc + c0 + (size_t)f * (c0 + c);
+                for (int r = c + g8; r < nb; r += 8) acc = __builtin_fma(Wc[r], tt[r], acc);
+            }
+            part[g8 * HB2_NB + c] = acc;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+            vf[c0 + tid] = s;
+            x[px[c0 + tid]] = s;
+            if (ac) ac[px[c0 + tid]] += s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace bpltv

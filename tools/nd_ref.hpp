@@ -1,0 +1,163 @@
+// nd_ref.hpp -- plain host restatement of the multifrontal numeric phase on the tree of csrc/nd_symbolic.hpp
+// (dense fronts, extend-add through cmap, partial Cholesky, forward / backward substitution in gather form).
+// Test infrastructure for tools/nd_host_check.cpp (g++) and tools/nd_unit.hip: it defines what the GPU kernels of
+// csrc/nd_kernels.hpp have to reproduce, on matrices small enough for a residual check beside it.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "../bpldenoising_amd/csrc/nd_symbolic.hpp"
+
+namespace ndref {
+using bpltv::NdNode;
+using bpltv::NdOrig;
+using bpltv::NdTree;
+
+struct Factor {
+    std::vector<double> fac;   // per node f x p: rows [0, p) = W = L11^-1 (lower, zeros above), rows [p, f) = L21
+    int fail = 0;
+};
+
+// planes[t][pixel]: A[pixel + off_t][pixel] (BandDiags convention)
+inline Factor factor(const NdTree& T, const std::vector<std::vector<double>>& planes) {
+    Factor F;
+    F.fac.assign((size_t)T.fac_doubles, 0.0);
+    std::vector<std::vector<double>> U(T.nodes.size());
+    for (int l = T.levels() - 1; l >= 0; --l)
+        for (int q = T.lvl_start[l]; q < T.lvl_start[l + 1]; ++q) {
+            const NdNode& v = T.nodes[q];
+            const int p = v.p, b = v.b, f = p + b;
+            std::vector<double> A((size_t)f * f, 0.0);   // column major, lower triangle
+            for (int e = 0; e < v.orig_cnt; ++e) {
+                const NdOrig& o = T.orig[v.orig_off + e];
+                A[o.r + (size_t)f * o.c] += planes[o.plane][o.pixel];
+            }
+            for (int ci = 0; ci < 2; ++ci) {
+                if (v.child[ci] < 0) continue;
+                const NdNode& ch = T.nodes[v.child[ci]];
+                const int* cm = &T.cmap[ch.cmap_off];
+                const std::vector<double>& Uc = U[v.child[ci]];
+                for (int j = 0; j < ch.b; ++j)
+                    for (int i = j; i < ch.b; ++i) A[cm[i] + (size_t)f * cm[j]] += Uc[i + (size_t)ch.b * j];
+                U[v.child[ci]].clear();
+                U[v.child[ci]].shrink_to_fit();
+            }
+            // partial Cholesky of the first p columns
+            for (int k = 0; k < p; ++k) {
+                double d = A[k + (size_t)f * k];
+                if (!(d > 0.0)) { if (!F.fail) F.fail = q + 1; d = 1.0; }
+                const double s = std::sqrt(d);
+                A[k + (size_t)f * k] = s;
+                for (int i = k + 1; i < f; ++i) A[i + (size_t)f * k] /= s;
+                for (int j = k + 1; j < f; ++j) {
+                    const double ljk = A[j + (size_t)f * k];
+                    if (ljk == 0.0) continue;
+                    for (int i = j; i < f; ++i) A[i + (size_t)f * j] -= A[i + (size_t)f * k] * ljk;
+                }
+            }
+            // W = L11^-1 by forward substitution on the identity
+            double* out = &F.fac[(size_t)v.fac_off];
+            for (int c = 0; c < p; ++c) {
+                std::vector<double> x(p, 0.0);
+                for (int r = c; r < p; ++r) {
+                    double acc = (r == c) ? 1.0 : 0.0;
+                    for (int k = c; k < r; ++k) acc -= A[r + (size_t)f * k] * x[k];
+                    x[r] = acc / A[r + (size_t)f * r];
+                }
+                for (int r = 0; r < p; ++r) out[r + (size_t)f * c] = x[r];
+                for (int r = p; r < f; ++r) out[r + (size_t)f * c] = A[r + (size_t)f * c];
+            }
+            U[q].assign((size_t)b * b, 0.0);
+            for (int j = 0; j < b; ++j)
+                for (int i = j; i < b; ++i) U[q][i + (size_t)b * j] = A[(p + i) + (size_t)f * (p + j)];
+        }
+    return F;
+}
+
+// x <- A^-1 x
+inline void solve(const NdTree& T, const Factor& F, std::vector<double>& x) {
+    std::vector<double> uv((size_t)T.uv_doubles, 0.0), y(T.n, 0.0);
+    for (int l = T.levels() - 1; l >= 0; --l)
+        for (int q = T.lvl_start[l]; q < T.lvl_start[l + 1]; ++q) {
+            const NdNode& v = T.nodes[q];
+            const int p = v.p, b = v.b, f = p + b;
+            std::vector<double> s(f, 0.0);
+            for (int ci = 0; ci < 2; ++ci) {
+                if (v.child[ci] < 0) continue;
+                const NdNode& ch = T.nodes[v.child[ci]];
+                for (int k = 0; k < ch.b; ++k) s[T.cmap[ch.cmap_off + k]] += uv[(size_t)ch.uv_off + k];
+            }
+            const double* fc = &F.fac[(size_t)v.fac_off];
+            std::vector<double> w(p), yp(p, 0.0);
+            for (int k = 0; k < p; ++k) w[k] = x[T.pix[v.piv_off + k]] - s[k];
+            for (int r = 0; r < p; ++r) {
+                double acc = 0.0;
+                for (int c = 0; c <= r; ++c) acc += fc[r + (size_t)f * c] * w[c];
+                yp[r] = acc;
+            }
+            for (int k = 0; k < p; ++k) y[T.pix[v.piv_off + k]] = yp[k];
+            for (int i = 0; i < b; ++i) {
+                double acc = s[p + i];
+                for (int c = 0; c < p; ++c) acc += fc[(p + i) + (size_t)f * c] * yp[c];
+                uv[(size_t)v.uv_off + i] = acc;
+            }
+        }
+    for (int l = 0; l < T.levels(); ++l)
+        for (int q = T.lvl_start[l]; q < T.lvl_start[l + 1]; ++q) {
+            const NdNode& v = T.nodes[q];
+            const int p = v.p, b = v.b, f = p + b;
+            const double* fc = &F.fac[(size_t)v.fac_off];
+            std::vector<double> z(p);
+            for (int c = 0; c < p; ++c) {
+                double acc = y[T.pix[v.piv_off + c]];
+                for (int i = 0; i < b; ++i) acc -= fc[(p + i) + (size_t)f * c] * x[T.pix[v.piv_off + p + i]];
+                z[c] = acc;
+            }
+            for (int c = 0; c < p; ++c) {   // x_p = W^T z
+                double acc = 0.0;
+                for (int r = c; r < p; ++r) acc += fc[r + (size_t)f * c] * z[r];
+                x[T.pix[v.piv_off + c]] = acc;
+            }
+        }
+}
+
+// random SPD matrix with the tree's stencil: planes[t][pixel]; entries of geometrically invalid pairs are zero
+inline std::vector<std::vector<double>> random_spd(const NdTree& T, unsigned seed, double big = 0.0) {
+    const int M = T.M, N = T.N, n = T.n;
+    std::vector<std::vector<double>> P(T.st.nd, std::vector<double>(n, 0.0));
+    unsigned long long s = seed * 2654435761ull + 12345;
+    auto rnd = [&]() {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)((s >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53);
+    };
+    std::vector<double> rowsum(n, 0.0);
+    for (int t = 1; t < T.st.nd; ++t)
+        for (int g = 0; g < n; ++g) {
+            const int i = g % M, j = g / M, a = i + T.st.di[t], c = j + T.st.dj[t];
+            if (a < 0 || a >= M || c < 0 || c >= N) continue;
+            double v = -(0.1 + rnd());
+            if (big > 0.0 && rnd() < 0.2) v *= big;   // a few strongly coupled pairs (the active-set weight)
+            const int g2 = a + M * c, lo = g < g2 ? g : g2;   // stored at the pixel of smaller linear index
+            P[t][lo] = v;
+            rowsum[g] += std::fabs(v);
+            rowsum[g2] += std::fabs(v);
+        }
+    for (int g = 0; g < n; ++g) P[0][g] = rowsum[g] + 1.0 + rnd();
+    return P;
+}
+
+// y = A x with the planes
+inline void matvec(const NdTree& T, const std::vector<std::vector<double>>& P, const std::vector<double>& x, std::vector<double>& y) {
+    const int M = T.M, N = T.N, n = T.n;
+    y.assign(n, 0.0);
+    for (int g = 0; g < n; ++g) y[g] = P[0][g] * x[g];
+    for (int t = 1; t < T.st.nd; ++t)
+        for (int g = 0; g < n; ++g) {
+            const int i = g % M, j = g / M, a = i + T.st.di[t], c = j + T.st.dj[t];
+            if (a < 0 || a >= M || c < 0 || c >= N) continue;
+            const int g2 = a + M * c, lo = g < g2 ? g : g2;
+            y[g] += P[t][lo] * x[g2];
+            y[g2] += P[t][lo] * x[g];
+        }
+}
+}  // namespace ndref
