@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -19,6 +20,7 @@
 #include "adjoint_hbm_kernels.hpp"
 #include "hb_band_solver.hpp"
 #include "hb_lu_solver.hpp"
+#include "nd_solver.hpp"
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
 #include "pdhg_kernels.hpp"
@@ -160,8 +162,11 @@ struct bpltv_handle {
     bool adj_ready = false;   // common workspace
     bool band_ready = false;  // banded Cholesky workspace (LDS window or HBM band)
     bool bcr_ready = false;   // block cyclic reduction workspace
-    double* d_bcr = nullptr;  // 7 block arrays [O][N][MP*MP]: Linv, LinvT, C, XA, XAT, XB, XBT
+    double* d_bcr = nullptr;  // 7 block arrays [Oc][N][MP*MP]: Linv, LinvT, C, XA, XAT, XB, XBT
     int bcr_MP = 0;
+    int bcr_cap = 0;          // images the block arrays hold (the adjoint runs in groups of at most that many)
+    NdSolver nd;              // nested-dissection (multifrontal) Cholesky: wide images (nd_solver.hpp)
+    NdSolver nd_sr;           // the same for the 13-point stencil of the sum-of-regularisers model
     double* d_coef = nullptr;   // 8 planes
     double* d_band4 = nullptr;  // 4 planes
     double* d_L = nullptr;
@@ -744,41 +749,97 @@ size_t adj_factor_lds(int M, int NB) {  // ring (bw+NB) x (bw+1) + panel NB x (b
     return sizeof(double) * ((size_t)(M + NB) * (M + 1) + (size_t)NB * (M + NB));
 }
 
+// hipMalloc a list of buffers; on failure every buffer of the list is freed again and its pointer cleared, so a
+// failed workspace allocation leaves nothing behind (a retry starts from scratch).
+struct AllocReq { void** p; size_t bytes; };
+int alloc_all(bpltv_t* h, std::initializer_list<AllocReq> reqs, const char* what) {
+    for (const AllocReq& r : reqs) *r.p = nullptr;
+    for (const AllocReq& r : reqs) {
+        const hipError_t e = hipMalloc(r.p, r.bytes);
+        if (e != hipSuccess) {
+            *r.p = nullptr;
+            for (const AllocReq& q : reqs)
+                if (*q.p) { (void)hipFree(*q.p); *q.p = nullptr; }
+            (void)hipGetLastError();
+            return set_err(h, e == hipErrorOutOfMemory ? BPLTV_E_NOMEM : BPLTV_E_HIP, "%s: hipMalloc of %.1f MB failed: %s", what, r.bytes / 1e6,
+                           hipGetErrorString(e));
+        }
+    }
+    return BPLTV_OK;
+}
+
 int adj_alloc(bpltv_t* h) {
     if (h->adj_ready) return BPLTV_OK;
     const size_t tot = h->tot;
-    HIPCHK(h, hipMalloc((void**)&h->d_coef, 8 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_band4, 4 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_p, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_r, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_gpix, tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_resn, 4 * (size_t)h->O * (1 + RESN_BLK) * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_fail, (size_t)h->O * sizeof(int)));
+    const int rc = alloc_all(h, {{(void**)&h->d_coef, 8 * tot * sizeof(double)},
+                                 {(void**)&h->d_band4, 4 * tot * sizeof(double)},
+                                 {(void**)&h->d_p, tot * sizeof(double)},
+                                 {(void**)&h->d_r, tot * sizeof(double)},
+                                 {(void**)&h->d_gpix, tot * sizeof(double)},
+                                 {(void**)&h->d_resn, 4 * (size_t)h->O * (1 + RESN_BLK) * sizeof(double)},
+                                 {(void**)&h->d_fail, (size_t)h->O * sizeof(int)}}, "adjoint workspace");
+    if (rc) return rc;
     h->adj_ready = true;
+    return BPLTV_OK;
+}
+
+// HBM the factor workspace of the adjoint may take: BPLTV_ADJ_BUDGET_MB (a test aid: forces the gradient to run in
+// image groups), else what is free now plus what this handle already holds for it, minus a 2 GB reserve.
+size_t adj_budget(size_t held) {
+    const char* e = getenv("BPLTV_ADJ_BUDGET_MB");
+    if (e && atof(e) > 0.0) return (size_t)(atof(e) * 1e6);
+    size_t freeb = 0, totalb = 0;
+    (void)hipMemGetInfo(&freeb, &totalb);
+    const size_t reserve = 2ull << 30;
+    return freeb + held > reserve ? freeb + held - reserve : 0;
+}
+// images per group so that `per_image` bytes each fit the budget: all O when they fit, at least one
+int adj_group(bpltv_t* h, size_t per_image, size_t held, const char* what, int* Oc) {
+    const size_t budget = adj_budget(held);
+    size_t g = per_image ? budget / per_image : (size_t)h->O;
+    if (g < 1)
+        return set_err(h, BPLTV_E_NOMEM, "adjoint gradient (%s): the factor workspace of ONE %dx%d image needs %.2f GB of HBM, %.2f GB available",
+                       what, h->M, h->N, per_image / 1e9, budget / 1e9);
+    *Oc = (int)std::min<size_t>(g, (size_t)h->O);
     return BPLTV_OK;
 }
 
 // Block cyclic reduction (adjoint_bcr_kernels.hpp) applies to M <= 128, N >= 2; its seven block arrays
 // take 7*N*MP^2 doubles per image (117 MB for 128^2; the odd blocks' slots stay unused because level 0
-// runs in operator form).
+// runs in operator form).  Workspace for groups of *Oc images.
 bool bcr_applicable(const bpltv_t* h) { return h->M <= BS_MP && h->N >= 2; }
 
-int bcr_alloc(bpltv_t* h) {
-    if (h->bcr_ready) return BPLTV_OK;
+int bcr_alloc(bpltv_t* h, int* Oc) {
     const int MP = (h->M + 15) / 16 * 16;
-    const size_t need = BcrArrays::doubles(h->M, h->N, h->O, MP) * sizeof(double);
-    size_t freeb = 0, totalb = 0;
-    (void)hipMemGetInfo(&freeb, &totalb);
-    if (need + (1ull << 30) > freeb)
-        return set_err(h, BPLTV_E_NOMEM, "adjoint gradient (block cyclic reduction): %.1f GB of HBM needed, %.1f GB free",
-                       need / 1e9, freeb / 1e9);
-    HIPCHK(h, hipMalloc((void**)&h->d_bcr, need));
+    const size_t per = BcrArrays::doubles(h->M, h->N, 1, MP) * sizeof(double);
+    int rc = adj_group(h, per, (size_t)h->bcr_cap * per, "block cyclic reduction", Oc);
+    if (rc) return rc;
+    if (h->bcr_cap >= *Oc) return BPLTV_OK;
+    if (h->d_bcr) (void)hipFree(h->d_bcr);
+    h->d_bcr = nullptr; h->bcr_cap = 0; h->bcr_ready = false;
+    rc = alloc_all(h, {{(void**)&h->d_bcr, (size_t)*Oc * per}}, "adjoint gradient (block cyclic reduction)");
+    if (rc) return rc;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr_potrf_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr_potrf_lds(BS_MP)));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&bcr0_schur_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bcr0_schur_lds(BS_MP)));
     h->bcr_MP = MP;
+    h->bcr_cap = *Oc;
     h->bcr_ready = true;
+    return BPLTV_OK;
+}
+
+// Nested-dissection Cholesky (nd_solver.hpp): tree built once per handle, workspace for groups of *Oc images.
+int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, int* Oc) {
+    if (!nd.built) {
+        const int rc = nd.build(h->M, h->N, st);
+        if (rc) { const std::string m = nd.err; nd.release(); return set_err(h, rc, "adjoint gradient (%s): %s", what, m.c_str()); }
+    }
+    const size_t per = nd.bytes_per_image();
+    int rc = adj_group(h, per, (size_t)nd.cap * per, what, Oc);
+    if (rc) return rc;
+    rc = nd.alloc(*Oc, h->stream);
+    if (rc) return set_err(h, rc, "adjoint gradient (%s): %s", what, nd.err.c_str());
     return BPLTV_OK;
 }
 
@@ -792,16 +853,18 @@ int band_alloc(bpltv_t* h) {
         (void)hipMemGetInfo(&freeb, &totalb);
         const size_t need = h->hb.bytes_needed(h->M, (int)h->npx, h->O);
         if (need + (2ull << 30) > freeb)
-            return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free)",
+            return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free); the nested-dissection factorisation (the default for this shape) needs a fraction of that and runs in image groups",
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
         const int rc = h->hb.alloc(h->M, (int)h->npx, h->O, h->stream);
         if (rc) return set_err(h, rc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
     }
+    int rc = BPLTV_OK;
     if (!h->adj_hbm) {
-        HIPCHK(h, hipMalloc((void**)&h->d_L, tot * W * sizeof(double)));
         const size_t nblk = (h->npx + SB - 1) / SB;
-        HIPCHK(h, hipMalloc((void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
-        HIPCHK(h, hipMalloc((void**)&h->d_invB, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)));
+        rc = alloc_all(h, {{(void**)&h->d_L, tot * W * sizeof(double)},
+                           {(void**)&h->d_invF, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)},
+                           {(void**)&h->d_invB, 2 * (size_t)h->O * nblk * SB * SB * sizeof(double)}}, "adjoint gradient (LDS band)");
+        if (rc) return rc;
     }
     {   // two-sided (twisted) factorisation: two workgroups per image meet in a dense middle block
         const AdjSplit sp = adj_split((int)h->npx, h->M);
@@ -810,10 +873,15 @@ int band_alloc(bpltv_t* h) {
                          sp.nm >= h->M && (size_t)sp.nm <= (size_t)h->M + 4;
         if (h->adj_twisted) {
             const size_t blk = (size_t)(h->M + ADJ_G) * (h->M + ADJ_G);
-            HIPCHK(h, hipMalloc((void**)&h->d_L1, tot * W * sizeof(double)));
-            HIPCHK(h, hipMalloc((void**)&h->d_dump, 2 * (size_t)h->O * blk * sizeof(double)));
-            HIPCHK(h, hipMalloc((void**)&h->d_Lm, (size_t)h->O * blk * sizeof(double)));
-            HIPCHK(h, hipMalloc((void**)&h->d_spill, 2 * (size_t)h->O * RING * sizeof(double)));
+            rc = alloc_all(h, {{(void**)&h->d_L1, tot * W * sizeof(double)},
+                               {(void**)&h->d_dump, 2 * (size_t)h->O * blk * sizeof(double)},
+                               {(void**)&h->d_Lm, (size_t)h->O * blk * sizeof(double)},
+                               {(void**)&h->d_spill, 2 * (size_t)h->O * RING * sizeof(double)}}, "adjoint gradient (LDS band, twisted)");
+            if (rc) {
+                for (double** q : {&h->d_L, &h->d_invF, &h->d_invB})
+                    if (*q) { (void)hipFree(*q); *q = nullptr; }
+                return rc;
+            }
             HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_mid_factor_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_mid_solve_kernel),
@@ -836,18 +904,28 @@ int band_alloc(bpltv_t* h) {
 enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3, ADJ_BAND_LU = 4, ADJ_ND = 5 };   // also bpltv_stats_t::adjoint_method
 
 // Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
-// reduction) and make sure its workspace exists.
-int adj_choose(bpltv_t* h, const bpltv_params& p, AdjMethod* out) {
+// reduction, 3 nested dissection), make sure its workspace exists and say in groups of how many images the gradient
+// runs (*Oc = O unless the factor workspace of all images does not fit: adj_group).
+// Automatic: block cyclic reduction for M <= 128 (every shipped dataset), the LDS-window band for the few shapes
+// just above (M <= 138, or N = 1), nested dissection for everything wider.
+int adj_choose(bpltv_t* h, const bpltv_params& p, AdjMethod* out, int* Oc) {
     const int want = p.reserved[4];
+    *Oc = h->O;
     if (want == 2 && !bcr_applicable(h))
         return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
                        h->M, h->N);
-    if (bcr_applicable(h) && want != 1) {
-        const int rc = bcr_alloc(h);
-        if (rc == BPLTV_OK) { *out = ADJ_BCR; return BPLTV_OK; }
-        if (!(rc == BPLTV_E_NOMEM && want == 0)) return rc;   // automatic choice: the band needs 7x less memory
+    if (want == 2 || (want == 0 && bcr_applicable(h))) {
+        const int rc = bcr_alloc(h, Oc);
+        if (rc == BPLTV_OK) *out = ADJ_BCR;
+        return rc;
     }
-    const int rc = band_alloc(h);
+    const bool lds_band = adj_factor_lds(h->M, 4) <= 160 * 1024;
+    if (want == 3 || (want == 0 && !lds_band)) {
+        const int rc = nd_alloc(h, h->nd, nd_stencil_tv(), "nested dissection", Oc);
+        if (rc == BPLTV_OK) *out = ADJ_ND;
+        return rc;
+    }
+    const int rc = band_alloc(h);   // whole batch at once (the HBM band path keeps its pipeline state per handle)
     if (rc) return rc;
     *out = h->adj_hbm ? ADJ_BAND_HBM : ADJ_BAND_LDS;
     return BPLTV_OK;
@@ -926,15 +1004,20 @@ void solve_band_lds(bpltv_t* h, double* vec, double* accv) {
 }
 
 // Adjoint gradient of the images (d_u, d_ubar) on the device; result (am*an doubles) -> d_out.
+// The images are processed in groups of at most Oc (adj_choose): coefficients, assembly, factorisation, solve and
+// refinement of a group use the factor workspace of the previous one; the per-pixel gradients of all images are
+// summed at the end, per image and in image order, so the result does not depend on the grouping (bitwise).
+// Reference: the per-image loop of /root/reference/src/TVLearningFunctionVec.jl:76-81,168-173 -- sequential, no limit.
 int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p,
                       double* d_out, double kappa_scale) {
     int rc = adj_alloc(h);
     if (rc) return rc;
     AdjMethod method;
-    rc = adj_choose(h, p, &method);
+    int Oc = h->O;
+    rc = adj_choose(h, p, &method, &Oc);
     if (rc) return rc;
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
-    const size_t tot = h->tot;
+    const size_t tot = h->tot, npx = h->npx;
     const int patch = !(am == 1 && an == 1);
     const double eps = 2.220446049250313e-16;
     double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
@@ -944,54 +1027,67 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     // Refinement sweeps: every sweep gains ~2 digits with the 1e14 active-set weight of the scalar gradient and
     // 4-5 digits with the 6.7e7 / 1e8 weights of the patch and regularised gradients, where the second sweep
     // already reaches rounding level (tools/gpu_refine.py).
-    // The HBM band path factors with true triangular solves (only its 128 x 128 diagonal blocks are inverted): one
-    // sweep already reaches the level the block-cyclic-reduction path needs two for (tools/gpu_refine_hbm.py,
-    // 1024^2: pixel map 3.6e-9 / patch 6e-11 / regularised 1e-16 from the converged value after ONE sweep, scalar
-    // 1.4e-9 after two), and every sweep costs two full substitutions of the 8.6 GB factor.
-    // The regularised systems (gamma = 1e8 instead of 1/eps) need none: 4e-10 / 1e-9 / 5e-11 from the converged
-    // value without a sweep, scaled residual <= 4e-12.
-    const int nref_default = (method == ADJ_BAND_HBM) ? (reg ? 0 : (patch ? 1 : 2)) : ((patch || reg) ? 2 : 3);
+    // The HBM band and nested-dissection paths solve with true triangular factors (only 128 x 128 diagonal blocks
+    // are inverted): one sweep already reaches the level the block-cyclic-reduction path needs two for
+    // (1024^2: pixel map 3.6e-9 / patch 6e-11 / regularised 1e-16 from the converged value after ONE sweep, scalar
+    // 1.4e-9 after two).  The regularised systems (gamma = 1e8 instead of 1/eps) need none: 4e-10 / 1e-9 / 5e-11 from
+    // the converged value without a sweep, scaled residual <= 4e-12.
+    const bool direct = (method == ADJ_BAND_HBM || method == ADJ_ND);
+    const int nref_default = direct ? (reg ? 0 : (patch ? 1 : 2)) : ((patch || reg) ? 2 : 3);
     const int nref = p.refine < 0 ? nref_default : p.refine;
-    AdjCoef C;
-    C.t1 = h->d_coef; C.t2 = h->d_coef + tot; C.c = h->d_coef + 2 * tot; C.kap = h->d_coef + 3 * tot;
-    C.h1 = h->d_coef + 4 * tot; C.h2 = h->d_coef + 5 * tot; C.s = h->d_coef + 6 * tot; C.rhs = h->d_coef + 7 * tot;
-    const int gpx = (int)((tot + 255) / 256);
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    // coefficients and the four diagonals of the matrix
-    hipLaunchKernelGGL(adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N,
-                       O, patch, reg, kact, C);
-    hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_band4);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
-    // factorisation
-    const BcrArrays bcr = BcrArrays::carve(h->d_bcr, M, N, O, h->bcr_MP);
-    if (method == ADJ_BCR) {
-        bcr_factor_band4_launch(h->stream, bcr, h->d_band4, M, N, O, h->bcr_MP, h->d_fail);
-    } else if (method == ADJ_BAND_HBM) {
-        rc = factor_band_hbm(h);
-        if (rc) return rc;
-    } else {
-        factor_band_lds(h);
+    int chunks = 0;
+    for (int c0 = 0; c0 < O; c0 += Oc, ++chunks) {
+        const int nimg = std::min(Oc, O - c0);
+        const size_t o0 = (size_t)c0 * npx, ctot = (size_t)nimg * npx;
+        AdjCoef C;   // coefficient planes of the group: the whole-batch planes at the group's first image
+        C.t1 = h->d_coef + o0; C.t2 = h->d_coef + tot + o0; C.c = h->d_coef + 2 * tot + o0; C.kap = h->d_coef + 3 * tot + o0;
+        C.h1 = h->d_coef + 4 * tot + o0; C.h2 = h->d_coef + 5 * tot + o0; C.s = h->d_coef + 6 * tot + o0; C.rhs = h->d_coef + 7 * tot + o0;
+        double* band4 = h->d_band4;   // the four diagonals of the group's matrices, planes of nimg * npx doubles
+        double *dp = h->d_p + o0, *dr = h->d_r + o0, *dg = h->d_gpix + o0;
+        int* dfail = h->d_fail + c0;
+        const int gpx = (int)((ctot + 255) / 256);
+        hipLaunchKernelGGL(adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u + o0, d_ubar + o0, h->d_alpha, am, an, M, N,
+                           nimg, patch, reg, kact, C);
+        hipLaunchKernelGGL(adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, nimg, band4);
+        // factorisation
+        const BcrArrays bcr = BcrArrays::carve(h->d_bcr, M, N, nimg, h->bcr_MP);
+        if (method == ADJ_BCR) {
+            bcr_factor_band4_launch(h->stream, bcr, band4, M, N, nimg, h->bcr_MP, dfail);
+        } else if (method == ADJ_ND) {
+            const int r2 = h->nd.factor(band4, ctot, nimg, dfail);
+            if (r2) return set_err(h, r2, "adjoint gradient (nested dissection): %s", h->nd.err.c_str());
+        } else if (method == ADJ_BAND_HBM) {
+            rc = factor_band_hbm(h);
+            if (rc) return rc;
+        } else {
+            factor_band_lds(h);
+        }
+        HIPCHK(h, hipGetLastError());
+        auto solve = [&](double* vec, double* accv) {
+            if (method == ADJ_BCR) bcr_solve_launch(h->stream, bcr, M, N, nimg, h->bcr_MP, vec, accv, band4);
+            else if (method == ADJ_ND) (void)h->nd.solve(vec, accv, nimg);
+            else if (method == ADJ_BAND_HBM) solve_band_hbm(h, vec, accv);
+            else solve_band_lds(h, vec, accv);
+        };
+        // solve + iterative refinement against the matrix-free operator
+        HIPCHK(h, hipMemcpyAsync(dp, C.rhs, ctot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        solve(dp, nullptr);
+        for (int it = 0; it < nref; ++it) {
+            hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, dr);
+            solve(dr, dp);
+        }
+        hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, dr);
+        double* resn_part = h->d_resn + 4 * (size_t)O + 4 * (size_t)c0 * RESN_BLK;
+        hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, nimg), dim3(256), 0, h->stream, dr, C.rhs, band4, (int)npx, resn_part);
+        hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * nimg + 63) / 64), dim3(64), 0, h->stream, resn_part, nimg,
+                           h->d_resn + 4 * (size_t)c0);
+        // gradient per pixel
+        hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, patch, reg, dg);
+        HIPCHK(h, hipGetLastError());
     }
-    HIPCHK(h, hipGetLastError());
-    auto solve = [&](double* vec, double* accv) {
-        if (method == ADJ_BCR) bcr_solve_launch(h->stream, bcr, M, N, O, h->bcr_MP, vec, accv, h->d_band4);
-        else if (method == ADJ_BAND_HBM) solve_band_hbm(h, vec, accv);
-        else solve_band_lds(h, vec, accv);
-    };
-    // solve + iterative refinement against the matrix-free operator
-    HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    solve(h->d_p, nullptr);
-    for (int it = 0; it < nref; ++it) {
-        hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
-        solve(h->d_r, h->d_p);
-    }
-    hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_r);
-    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_band4, (int)h->npx,
-                       h->d_resn + 4 * (size_t)O);
-    hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * O + 63) / 64), dim3(64), 0, h->stream, h->d_resn + 4 * (size_t)O, O, h->d_resn);
-    // gradient per pixel, then per parameter
-    hipLaunchKernelGGL(adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg,
-                       h->d_gpix);
+    // ... then per parameter, over all images
     if (am == M && an == N && !(M == 1 && N == 1)) {  // pixelwise parameter map: plain sum over images
         hipLaunchKernelGGL(map_sum_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, h->stream, h->d_gpix, h->npx, O,
                            d_out);
@@ -1015,13 +1111,14 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
     h->st.adjoint_method = (int)method;
+    h->st.adjoint_chunks = chunks;
     h->st.hb_sync = (method == ADJ_BAND_HBM) ? (h->hb.value_sync ? 2 : 1) : 0;
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
             return set_err(h, BPLTV_E_NUMERIC, "adjoint Cholesky: non-positive pivot at %s %d of image %d",
-                           method == ADJ_BCR ? "block" : "column", fail[k] - 1, k);
+                           method == ADJ_BCR ? "block" : (method == ADJ_ND ? "front" : "column"), fail[k] - 1, k);
         const double* q = &resn[4 * (size_t)k];
         const double raw = std::sqrt(q[0]) / (q[1] > 0 ? std::sqrt(q[1]) : 1.0);
         const double scl = std::sqrt(q[2]) / (q[3] > 0 ? std::sqrt(q[3]) : 1.0);
@@ -1094,7 +1191,7 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
     if (int prc = check_params(h, p)) return prc;
     int rc = upload_alpha(h, alpha, am, an);
     if (rc) return rc;
-    if (h->band_ready && h->adj_hbm && p.reserved[4] != 2) {   // wide images: zero the band while the PDHG solve runs
+    if (h->band_ready && h->adj_hbm && p.reserved[4] == 1) {   // HBM band path: zero the band while the PDHG solve runs
         const int prc = h->hb.prefill_async();
         if (prc) return set_err(h, prc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
     }
@@ -1384,6 +1481,7 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
     h->st.adjoint_method = lu ? (int)ADJ_BAND_LU : (int)ADJ_BAND_HBM;
+    h->st.adjoint_chunks = 1;
     h->st.hb_sync = lu ? 0 : (h->hb_sr.value_sync ? 2 : 1);
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
@@ -1879,6 +1977,8 @@ int bpltv_destroy(bpltv_t* h) {
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     h->hb.release();
+    h->nd.release();
+    h->nd_sr.release();
     h->hb_sr.release();
     h->lu_sr.release();
     if (h->d_srdiagU) (void)hipFree(h->d_srdiagU);

@@ -178,16 +178,21 @@ def test_breakdown_retry_is_visible_and_arguments_are_validated(gpu_solver_cls):
 @pytest.mark.parametrize("shape,alpha", [((2, 40, 200), 0.1), ((1, 70, 150), np.array([[0.06, 0.15], [0.1, 0.2]])),
                                          ((1, 36, 160), "map"), ((1, 45, 139), 0.08), ((3, 20, 257), "map")],
                          ids=["scalar200", "patch150", "map160", "scalar139_odd_band", "map257_three_images"])
-def test_wide_images_use_the_hbm_band_path(gpu_solver_cls, oracle, shape, alpha):
-    """M > 138 does not fit the LDS window: the band is factored in place in HBM (one launch pair
-    per panel).  Same reduced system, same tolerance against the oracle."""
+@pytest.mark.parametrize("method", ["nd", "band"])
+def test_wide_images_use_the_hbm_band_path(gpu_solver_cls, oracle, shape, alpha, method):
+    """M > 138 does not fit the LDS window.  Default: the nested-dissection (multifrontal) Cholesky (O(M^3) flop);
+    cross-check: the band factored in place in HBM (O(M^4), `adjoint_method="band"`).  Same reduced system, same
+    tolerance against the oracle."""
     O, N, M = shape
     ub, f = synth_batch(O, N, M, seed=70 + M)
     if isinstance(alpha, str):
         alpha = 0.05 + 0.1 * np.random.default_rng(4).random((N, M))
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
-    u, cost, grad = s.evaluate(alpha, 0.1, maxiter=500)
+    kw = {} if method == "nd" else {"adjoint_method": "band"}       # nd is the automatic choice for this shape
+    u, cost, grad = s.evaluate(alpha, 0.1, maxiter=500, **kw)
+    st = s.stats()
+    assert st["adjoint_method"] == ("nd" if method == "nd" else "band-hbm") and st["adjoint_residual"] <= 1e-8, st
     u0 = oracle.pdhg(f, alpha, maxiter=500)
     g0 = oracle.gradient(alpha, u0, ub)
     assert np.array_equal(u, u0)
@@ -195,7 +200,7 @@ def test_wide_images_use_the_hbm_band_path(gpu_solver_cls, oracle, shape, alpha)
         assert np.allclose(grad, g0, rtol=1e-4, atol=2e-6 * np.abs(g0).max()) and np.isclose(grad.sum(), g0.sum(), rtol=1e-6)
     else:
         assert np.allclose(grad, g0, rtol=2e-6, atol=1e-9)
-    _, _, greg = s.evaluate(alpha, 0.0, maxiter=500)
+    _, _, greg = s.evaluate(alpha, 0.0, maxiter=500, **kw)
     gr0 = oracle.gradient(alpha, u0, ub, reg=True)
     assert np.allclose(greg, gr0, rtol=1e-6, atol=1e-8 * np.abs(gr0).max())
     s.close()
@@ -455,28 +460,30 @@ def test_band_solver_unit_checks(gpu_solver_cls):
 
 
 def test_full_size_gradient_properties_1024(gpu_solver_cls):
-    """BASELINE config 5 image size (1024 x 1024, HBM-resident band, 8.6 GB factor): properties that need
-    no oracle run -- the refined adjoint solve reaches the residual level of the 128^2 cases, the
-    stand-alone gradient entry reproduces the gradient of evaluate from its (u, ubar), and the
-    regularised branch (delta <= delta_t) gives a finite, different value."""
+    """BASELINE config 5 image size (1024 x 1024): properties that need no oracle run -- the refined adjoint solve
+    reaches the residual level of the 128^2 cases, the stand-alone gradient entry reproduces the gradient of evaluate
+    from its (u, ubar), and the two factorisations of the same system -- nested dissection (default, 0.65 GB of factor)
+    and the HBM-resident band (8.6 GB) -- give the same gradient."""
     N = M = 1024
     ub, f = synth_batch(1, N, M, seed=12)
     s = gpu_solver_cls(M, N, 1)
     s.set_data(ub, f)
     u, cost, g = s.evaluate(0.1, 0.1, maxiter=300)
     st = s.stats()
-    assert st["adjoint_method"] == "band-hbm" and st["reg_gradient_used"] == 0
+    assert st["adjoint_method"] == "nd" and st["reg_gradient_used"] == 0 and st["adjoint_chunks"] == 1
     assert np.isfinite(g) and st["adjoint_residual"] <= 1e-8, st
     assert np.isclose(cost, 0.5 * np.sum((u - ub) ** 2), rtol=1e-12)
     g2 = s.gradient(u, ub, 0.1)
     assert np.isclose(g2, g, rtol=1e-12), (g, g2)            # same kernels, same data: reproducible
+    gb = s.gradient(u, ub, 0.1, adjoint_method="band")
+    assert s.stats()["adjoint_method"] == "band-hbm" and np.isclose(gb, g, rtol=1e-6), (g, gb)
     s.close()
 
 
 def test_config5_share_evaluate_8x1024(gpu_solver_cls):
     """BASELINE config 5's share of one GPU through the whole learning function: 8 x 1024 x 1024, pixelwise
-    alpha, PDHG + loss + the HBM-band adjoint (8 x 8.6 GB factors resident).  Properties that need
-    no oracle run: the factorisation is the HBM band, the scaled residual passes the gate, the loss equals the
+    alpha, PDHG + loss + the nested-dissection adjoint (8 x 0.65 GB factors).  Properties that need
+    no oracle run: the factorisation is nested dissection, the scaled residual passes the gate, the loss equals the
     host sum, the pixel-map gradient is finite with the sign of the reference (increasing alpha from a
     small value lowers the loss on noisy data: sum of the map gradient < 0), and the stand-alone gradient entry
     reproduces it from (u, ubar)."""
@@ -488,8 +495,9 @@ def test_config5_share_evaluate_8x1024(gpu_solver_cls):
     s.set_data(ub, f)
     u, cost, g = s.evaluate(amap, 0.1, maxiter=400)
     st = s.stats()
-    assert st["adjoint_method"] == "band-hbm" and st["adjoint_attempts"] == 1
+    assert st["adjoint_method"] == "nd" and st["adjoint_attempts"] == 1 and st["adjoint_chunks"] == 1
     assert st["adjoint_residual"] <= 1e-8, st
+    assert st["adjoint_ms"] < 150.0, st["adjoint_ms"]      # the banded Cholesky needed 500 ms here
     assert g.shape == (N, M) and np.isfinite(g).all() and g.sum() < 0
     assert np.isclose(cost, 0.5 * np.sum((u - ub) ** 2), rtol=1e-12)
     g2 = s.gradient(u, ub, amap)
@@ -531,3 +539,98 @@ def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
         res.append(g)
         s.close()
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
+def test_nd_solver_unit_checks(gpu_solver_cls):
+    """tools/nd_unit.hip: the nested-dissection Cholesky (fronts in LDS, fronts in HBM with multi-panel pivot blocks,
+    gather-form substitutions) against the host restatement tools/nd_ref.hpp: factor entries and solutions on random
+    SPD stencil matrices, several images per call, both stencils."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "_bin", "nd_unit")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("shape,alpha,method,budget_mb", [
+    ((7, 128, 128), 0.1, "bcr", 300.0),                                  # 117 MB per image: groups of 2
+    ((5, 48, 300), "map", "nd", None),                                   # budget computed below: groups of 2
+    ((5, 128, 128), np.array([[0.06, 0.15], [0.1, 0.2]]), "nd", None),   # nested dissection on a small image
+], ids=["bcr_scalar", "nd_map_wide", "nd_patch_128"])
+def test_adjoint_in_image_groups_is_bitwise_the_whole_batch(gpu_solver_cls, monkeypatch, shape, alpha, method, budget_mb):
+    """When the factor workspace of all images does not fit in HBM the gradient runs in image groups (the
+    reference's loop is sequential and has no such limit, /root/reference/src/TVLearningFunctionVec.jl:76-81).
+    BPLTV_ADJ_BUDGET_MB forces that on a small case: cost and gradient are BITWISE those of the whole batch at once
+    (per-image results do not depend on the other images of a launch; sums run per image, in image order)."""
+    O, N, M = shape
+    ub, f = synth_batch(O, N, M, seed=5 + M)
+    if isinstance(alpha, str):
+        alpha = 0.05 + 0.1 * np.random.default_rng(8).random((N, M))
+    monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB", raising=False)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u0, c0, g0 = s.evaluate(alpha, 0.1, maxiter=300, adjoint_method=method)
+    st0 = s.stats()
+    assert st0["adjoint_chunks"] == 1 and st0["adjoint_method"] == method
+    rows0 = s.per_image() if np.size(alpha) < M * N else None
+    s.close()
+    if budget_mb is None:       # two images' worth of this shape's nested-dissection workspace
+        import ctypes as C
+        budget_mb = 2.5 * _nd_bytes_per_image(M, N) / 1e6
+    monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "%.3f" % budget_mb)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u1, c1, g1 = s.evaluate(alpha, 0.1, maxiter=300, adjoint_method=method)
+    st1 = s.stats()
+    assert st1["adjoint_chunks"] == (O + 1) // 2, st1
+    assert np.array_equal(u1, u0) and c1 == c0 and np.array_equal(np.asarray(g1), np.asarray(g0))
+    if rows0 is not None:
+        assert np.array_equal(s.per_image(), rows0)
+    _, _, r1 = s.evaluate(alpha, 0.0, maxiter=300, adjoint_method=method)       # gradient_reg in groups too
+    monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB")
+    s.close()
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    _, _, r0 = s.evaluate(alpha, 0.0, maxiter=300, adjoint_method=method)
+    assert np.array_equal(np.asarray(r1), np.asarray(r0))
+    # a budget below one image's workspace is an error that says so, not a crash
+    monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "0.001")
+    from bpldenoising_amd._lib import BpltvError
+    s2 = gpu_solver_cls(M, N, O)
+    s2.set_data(ub, f)
+    with pytest.raises(BpltvError) as e:
+        s2.evaluate(alpha, 0.1, maxiter=10, adjoint_method=method)
+    assert e.value.code == 5 and "ONE" in str(e.value)
+    s2.close()
+    s.close()
+
+
+def _nd_bytes_per_image(M, N):
+    """Workspace of the nested-dissection solver per image, from the host check tool (the same symbolic code)."""
+    import os, re, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "_bin", "nd_host_check")
+    out = subprocess.run([exe, "bytes", str(M), str(N)], capture_output=True, text=True, timeout=120).stdout
+    return float(re.search(r"bytes_per_image tv (\d+)", out).group(1))
+
+
+def test_config5_whole_batch_evaluate_64x1024(gpu_solver_cls):
+    """BASELINE config 5's WHOLE batch on one GPU: 64 x 1024 x 1024, pixelwise alpha -- PDHG state 4 GB, adjoint
+    planes 8 GB, nested-dissection factors 64 x 0.94 GB.  The banded path returned BPLTV_E_NOMEM here (8.6 GB per
+    image); the reference's per-image loop has no such limit.  Few iterations: this is about capacity."""
+    O, N, M = 64, 1024, 1024
+    rng = np.random.default_rng(1)
+    base_ub, base_f = synth_batch(4, N, M, seed=9)
+    idx = np.arange(O) % 4
+    ub = base_ub[idx] * (1.0 - 0.01 * (np.arange(O) // 4))[:, None, None]
+    f = np.clip(base_f[idx] + 0.002 * rng.standard_normal((O, 1, 1)), 0, 1)
+    jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+    amap = 0.02 + 0.01 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u, cost, g = s.evaluate(amap, 0.1, maxiter=40, fetch_u=False)
+    st = s.stats()
+    assert st["adjoint_method"] == "nd" and st["adjoint_residual"] <= 1e-8, st
+    assert g.shape == (N, M) and np.isfinite(g).all() and np.isfinite(cost)
+    s.close()

@@ -5,9 +5,18 @@
 // large grid (fronts per level, fill, flop).
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include "nd_ref.hpp"
 
 int main(int argc, char** argv) {
+    if (argc == 4 && std::string(argv[1]) == "bytes") {   // workspace per image of the device solver for an M x N grid
+        const int M = atoi(argv[2]), N = atoi(argv[3]);
+        for (int sr = 0; sr < 2; ++sr) {
+            const bpltv::NdTree T = bpltv::nd_build(M, N, sr ? bpltv::nd_stencil_sr() : bpltv::nd_stencil_tv(), getenv("BPLTV_ND_LEAF") ? atoi(getenv("BPLTV_ND_LEAF")) : 32);
+            printf("bytes_per_image %s %lld\n", sr ? "sr" : "tv", (long long)(8 * (T.fac_doubles + T.ws_doubles[0] + T.ws_doubles[1] + T.uv_doubles + T.n)));
+        }
+        return 0;
+    }
     const int shapes[][2] = {{1, 1}, {3, 1}, {1, 7}, {2, 2}, {5, 4}, {16, 16}, {33, 17}, {40, 64}, {7, 130}, {96, 50}, {128, 128}};
     int bad = 0;
     for (int sr = 0; sr < 2; ++sr)
