@@ -181,7 +181,7 @@ struct bpltv_handle {
     double *d_u2 = nullptr, *d_ubar2 = nullptr;  // staging for bpltv_gradient
     // sum-of-regularisers model (sumregs_kernels.hpp): state and adjoint workspace, allocated on first use
     double* d_sr[2][7] = {{nullptr}, {nullptr}};   // x, yf1, yf2, yb1, yb2, yc1, yc2; two sets (ping-pong)
-    bool sr_ready = false, sr_adj_ready = false;
+    bool sr_ready = false, sr_adj_ready = false, sr_band_ready = false;
     int last_slices = 1;                            // parameter slices of the last evaluate: 1 (TV) or 3
     int sr_result_buf = 0;
     bool sr_has_result = false;
@@ -906,21 +906,21 @@ enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3, ADJ_BAND_LU = 
 // Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
 // reduction, 3 nested dissection), make sure its workspace exists and say in groups of how many images the gradient
 // runs (*Oc = O unless the factor workspace of all images does not fit: adj_group).
-// Automatic: block cyclic reduction for M <= 128 (every shipped dataset), the LDS-window band for the few shapes
-// just above (M <= 138, or N = 1), nested dissection for everything wider.
+// Automatic = nested dissection for every shape: it needs the fewest flop and the least memory at every size measured
+// (10 x 128^2: factor + solve 0.66 + 0.20 ms against 1.0 + 0.16 ms per solve of block cyclic reduction; 8 x 1024^2:
+// 31 + 6 ms against 350 + 70 ms of the HBM band).  The other three stay selectable as cross-checks.
 int adj_choose(bpltv_t* h, const bpltv_params& p, AdjMethod* out, int* Oc) {
     const int want = p.reserved[4];
     *Oc = h->O;
-    if (want == 2 && !bcr_applicable(h))
-        return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
-                       h->M, h->N);
-    if (want == 2 || (want == 0 && bcr_applicable(h))) {
+    if (want == 2) {
+        if (!bcr_applicable(h))
+            return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction needs M <= %d and N >= 2 (M = %d, N = %d)", BS_MP,
+                           h->M, h->N);
         const int rc = bcr_alloc(h, Oc);
         if (rc == BPLTV_OK) *out = ADJ_BCR;
         return rc;
     }
-    const bool lds_band = adj_factor_lds(h->M, 4) <= 160 * 1024;
-    if (want == 3 || (want == 0 && !lds_band)) {
+    if (want == 0 || want == 3) {
         const int rc = nd_alloc(h, h->nd, nd_stencil_tv(), "nested dissection", Oc);
         if (rc == BPLTV_OK) *out = ADJ_ND;
         return rc;
@@ -1364,34 +1364,47 @@ int sr_adj_alloc(bpltv_t* h) {
     if (rc) return rc;
     if (h->sr_adj_ready) return BPLTV_OK;
     const size_t tot = h->tot;
-    size_t freeb = 0, totalb = 0;
-    (void)hipMemGetInfo(&freeb, &totalb);
-    const int n = (int)h->npx, bw = std::min(2 * h->M, n - 1);
-    const size_t need = h->hb_sr.bytes_needed(bw, n, h->O) + (19 + 7 + 6 + 3) * tot * sizeof(double);
-    if (need + (2ull << 30) > freeb)
-        return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint: %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
-    HIPCHK(h, hipMalloc((void**)&h->d_srcoef, 19 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_srdiag, 7 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_srw, 6 * tot * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->d_srgpix, 3 * tot * sizeof(double)));
-    rc = h->hb_sr.alloc(bw, n, h->O, h->stream);
-    if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    rc = alloc_all(h, {{(void**)&h->d_srcoef, 19 * tot * sizeof(double)},
+                       {(void**)&h->d_srdiag, 7 * tot * sizeof(double)},
+                       {(void**)&h->d_srw, 6 * tot * sizeof(double)},
+                       {(void**)&h->d_srgpix, 3 * tot * sizeof(double)}}, "sum-of-regularisers adjoint workspace");
+    if (rc) return rc;
     h->sr_adj_ready = true;
     return BPLTV_OK;
 }
 
+// HBM band solver of the 13-point system (bandwidth 2M), whole batch: the cross-check of the nested-dissection path
+int sr_band_alloc(bpltv_t* h) {
+    if (h->sr_band_ready) return BPLTV_OK;
+    size_t freeb = 0, totalb = 0;
+    (void)hipMemGetInfo(&freeb, &totalb);
+    const int n = (int)h->npx, bw = std::min(2 * h->M, n - 1);
+    const size_t need = h->hb_sr.bytes_needed(bw, n, h->O);
+    if (need + (2ull << 30) > freeb)
+        return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint (HBM band): %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
+    const int rc = h->hb_sr.alloc(bw, n, h->O, h->stream);
+    if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    h->sr_band_ready = true;
+    return BPLTV_OK;
+}
+
+// Gradient of the sum-of-regularisers model.  Factorisations of its 13-point system: nested dissection (default,
+// separators two pixels wide, image groups when the workspace does not fit), the HBM band at bandwidth 2M
+// (params.reserved[4] = 1), and -- sumregs_gradient_reg with a patch parameter, whose row-scaled system is not
+// symmetric (SumRegsLearningFunction.jl:250) -- the banded LU.
 int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p, double* d_out,
                          double kappa_scale) {
     int rc = sr_adj_alloc(h);
     if (rc) return rc;
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
-    const size_t tot = h->tot, P = (size_t)am * an;
+    const size_t tot = h->tot, P = (size_t)am * an, npx = h->npx;
     const int patch = !(am == 1 && an == 1);
-    // sumregs_gradient_reg with a patch parameter (SumRegsLearningFunction.jl:250) scales the ROWS of the three terms
-    // with three different maps: not symmetric -> banded LU (hb_lu_solver.hpp) instead of the Cholesky path
     const char* force_lu = getenv("BPLTV_SR_FORCE_LU");   // test aid: the LU path on the symmetric systems too
     const bool rowsc = reg && patch;
     const bool lu = rowsc || (force_lu && force_lu[0] == '1');
+    if (p.reserved[4] == 2) return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction applies to the TV model only");
+    const bool band = !lu && p.reserved[4] == 1;
+    int Oc = O;
     if (lu) {
         if (rowsc && !(h->alpha_min > 0.0))
             return set_err(h, BPLTV_E_ARG, "sumregs_gradient_reg with a patch parameter needs every entry > 0 (min = %g)", h->alpha_min);
@@ -1402,61 +1415,80 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
             const size_t need = h->lu_sr.bytes_needed(bw, n, O) + 7 * tot * sizeof(double);
             if (need + (2ull << 30) > freeb)
                 return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint (banded LU): %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
-            HIPCHK(h, hipMalloc((void**)&h->d_srdiagU, 7 * tot * sizeof(double)));
+            rc = alloc_all(h, {{(void**)&h->d_srdiagU, 7 * tot * sizeof(double)}}, "sum-of-regularisers adjoint (banded LU)");
+            if (rc) return rc;
             const int rc2 = h->lu_sr.alloc(bw, n, O, h->stream);
-            if (rc2) return set_err(h, rc2, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
+            if (rc2) { (void)hipFree(h->d_srdiagU); h->d_srdiagU = nullptr; return set_err(h, rc2, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str()); }
             h->lu_sr_ready = true;
         }
+    } else if (band) {
+        rc = sr_band_alloc(h);
+        if (rc) return rc;
+    } else {
+        rc = nd_alloc(h, h->nd_sr, nd_stencil_sr(), "sum of regularisers, nested dissection", &Oc);
+        if (rc) return rc;
     }
     double kact = 1.0 / 2.220446049250313e-16;   // eps() in the vector AND the patch variant (:319, :389)
     const double kcap = p.kappa_cap > 0.0 ? p.kappa_cap : 1e14;
     if (kact > kcap) kact = kcap;
     kact *= kappa_scale;
     const int nref = p.refine < 0 ? (reg ? 1 : 2) : p.refine;
-    SrCoef C;
-    C.tot = tot;
-    C.t1 = h->d_srcoef; C.t2 = h->d_srcoef + 3 * tot; C.c = h->d_srcoef + 6 * tot; C.kap = h->d_srcoef + 9 * tot;
-    C.h1 = h->d_srcoef + 12 * tot; C.h2 = h->d_srcoef + 15 * tot; C.rhs = h->d_srcoef + 18 * tot;
-    const int gpx = (int)((tot + 255) / 256);
     HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(sr_adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u, d_ubar, h->d_alpha, am, an, M, N, O, patch, reg,
-                       kact, C);
-    const double* rowscale = rowsc ? h->d_alpha : nullptr;
-    if (lu) HIPCHK(h, hipMemsetAsync(h->d_srdiagU, 0, 7 * tot * sizeof(double), h->stream));
-    hipLaunchKernelGGL(sr_adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, O, h->d_srdiag, rowscale, am, an,
-                       lu ? h->d_srdiagU : (double*)nullptr);
     HIPCHK(h, hipMemsetAsync(h->d_fail, 0, sizeof(int) * O, h->stream));
-    BandDiags D;
-    D.planes = h->d_srdiag; D.tot = tot; D.nd = 7;
-    D.off[0] = 0; D.off[1] = 1; D.off[2] = 2; D.off[3] = M - 1; D.off[4] = M; D.off[5] = M + 1; D.off[6] = 2 * M;
-    if (lu) {
-        BandDiags DU = D;
-        DU.planes = h->d_srdiagU;
-        rc = h->lu_sr.factor(D, DU, h->d_fail);
-        if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
-    } else {
-        rc = h->hb_sr.factor(D, h->d_fail);
-        if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+    const double* rowscale = rowsc ? h->d_alpha : nullptr;
+    int chunks = 0;
+    for (int c0 = 0; c0 < O; c0 += Oc, ++chunks) {
+        const int nimg = std::min(Oc, O - c0);
+        const size_t o0 = (size_t)c0 * npx, ctot = (size_t)nimg * npx;
+        SrCoef C;   // planes keep the whole-batch stride C.tot; the group starts at its first image
+        C.tot = tot;
+        C.t1 = h->d_srcoef + o0; C.t2 = h->d_srcoef + 3 * tot + o0; C.c = h->d_srcoef + 6 * tot + o0; C.kap = h->d_srcoef + 9 * tot + o0;
+        C.h1 = h->d_srcoef + 12 * tot + o0; C.h2 = h->d_srcoef + 15 * tot + o0; C.rhs = h->d_srcoef + 18 * tot + o0;
+        double *diag = h->d_srdiag + o0, *diagU = lu ? h->d_srdiagU + o0 : nullptr, *w = h->d_srw + o0, *gp = h->d_srgpix + o0;
+        double *dp = h->d_p + o0, *dr = h->d_r + o0;
+        int* dfail = h->d_fail + c0;
+        const int gpx = (int)((ctot + 255) / 256);
+        hipLaunchKernelGGL(sr_adj_setup_kernel, dim3(gpx), dim3(256), 0, h->stream, d_u + o0, d_ubar + o0, h->d_alpha, am, an, M, N, nimg,
+                           patch, reg, kact, C);
+        if (lu) HIPCHK(h, hipMemsetAsync(h->d_srdiagU, 0, 7 * tot * sizeof(double), h->stream));
+        hipLaunchKernelGGL(sr_adj_assemble_kernel, dim3(gpx), dim3(256), 0, h->stream, C, M, N, nimg, diag, rowscale, am, an, diagU);
+        BandDiags D;
+        D.planes = diag; D.tot = tot; D.nd = 7;
+        D.off[0] = 0; D.off[1] = 1; D.off[2] = 2; D.off[3] = M - 1; D.off[4] = M; D.off[5] = M + 1; D.off[6] = 2 * M;
+        if (lu) {
+            BandDiags DU = D;
+            DU.planes = diagU;
+            rc = h->lu_sr.factor(D, DU, dfail);
+            if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
+        } else if (band) {
+            rc = h->hb_sr.factor(D, dfail);
+            if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
+        } else {
+            rc = h->nd_sr.factor(diag, tot, nimg, dfail);
+            if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (nested dissection): %s", h->nd_sr.err.c_str());
+        }
+        auto residual = [&](double* out) {
+            hipLaunchKernelGGL(sr_adj_flux_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, w);
+            hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, w, M, N, nimg, out, rowscale, am, an);
+        };
+        auto solve = [&](double* v, double* acc) {
+            if (lu) h->lu_sr.solve(v, acc, h->d_gpix);
+            else if (band) h->hb_sr.solve(v, acc, h->d_gpix);
+            else (void)h->nd_sr.solve(v, acc, nimg);
+        };
+        HIPCHK(h, hipMemcpyAsync(dp, C.rhs, ctot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        solve(dp, nullptr);
+        for (int it = 0; it < nref; ++it) {
+            residual(dr);
+            solve(dr, dp);
+        }
+        residual(dr);
+        double* resn_part = h->d_resn + 4 * (size_t)O + 4 * (size_t)c0 * RESN_BLK;
+        hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, nimg), dim3(256), 0, h->stream, dr, C.rhs, diag, (int)npx, resn_part);
+        hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * nimg + 63) / 64), dim3(64), 0, h->stream, resn_part, nimg, h->d_resn + 4 * (size_t)c0);
+        hipLaunchKernelGGL(sr_adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, patch, reg, gp);
+        HIPCHK(h, hipGetLastError());
     }
-    auto residual = [&](double* out) {
-        hipLaunchKernelGGL(sr_adj_flux_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, h->d_srw);
-        hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, h->d_srw, M, N, O, out, rowscale,
-                           am, an);
-    };
-    auto solve = [&](double* v, double* acc) {
-        if (lu) h->lu_sr.solve(v, acc, h->d_gpix); else h->hb_sr.solve(v, acc, h->d_gpix);
-    };
-    HIPCHK(h, hipMemcpyAsync(h->d_p, C.rhs, tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    solve(h->d_p, nullptr);
-    for (int it = 0; it < nref; ++it) {
-        residual(h->d_r);
-        solve(h->d_r, h->d_p);
-    }
-    residual(h->d_r);
-    hipLaunchKernelGGL(adj_resnorm_kernel, dim3(RESN_BLK, O), dim3(256), 0, h->stream, h->d_r, C.rhs, h->d_srdiag, (int)h->npx,
-                       h->d_resn + 4 * (size_t)O);
-    hipLaunchKernelGGL(adj_resnorm_final_kernel, dim3((4 * O + 63) / 64), dim3(64), 0, h->stream, h->d_resn + 4 * (size_t)O, O, h->d_resn);
-    hipLaunchKernelGGL(sr_adj_gradpix_kernel, dim3(gpx), dim3(256), 0, h->stream, C, h->d_p, M, N, O, patch, reg, h->d_srgpix);
     if (am == M && an == N && !(M == 1 && N == 1)) {   // three pixelwise maps: plain sums over the images
         for (int k = 0; k < 3; ++k)
             hipLaunchKernelGGL(map_sum_kernel, dim3((unsigned)((h->npx + 255) / 256)), dim3(256), 0, h->stream, h->d_srgpix + k * tot,
@@ -1480,15 +1512,16 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
-    h->st.adjoint_method = lu ? (int)ADJ_BAND_LU : (int)ADJ_BAND_HBM;
-    h->st.adjoint_chunks = 1;
-    h->st.hb_sync = lu ? 0 : (h->hb_sr.value_sync ? 2 : 1);
+    h->st.adjoint_method = lu ? (int)ADJ_BAND_LU : (band ? (int)ADJ_BAND_HBM : (int)ADJ_ND);
+    h->st.adjoint_chunks = chunks;
+    h->st.hb_sync = band ? (h->hb_sr.value_sync ? 2 : 1) : 0;
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
             return set_err(h, BPLTV_E_NUMERIC, lu ? "sum-of-regularisers adjoint, banded LU without pivoting: zero, tiny or non-finite pivot at column %d of image %d"
-                                                  : "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d", fail[k] - 1, k);
+                                                  : (band ? "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d"
+                                                          : "sum-of-regularisers adjoint Cholesky: non-positive pivot at front %d of image %d"), fail[k] - 1, k);
         const double* q = &resn[4 * (size_t)k];
         const double raw = std::sqrt(q[0]) / (q[1] > 0 ? std::sqrt(q[1]) : 1.0);
         const double scl = std::sqrt(q[2]) / (q[3] > 0 ? std::sqrt(q[3]) : 1.0);

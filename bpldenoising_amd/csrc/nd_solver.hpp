@@ -178,7 +178,7 @@ struct NdSolver {
                 }
                 const int npan = (a.pmax + HB2_NB - 1) / HB2_NB;
                 for (int k = 0; k < npan; ++k) {
-                    hipLaunchKernelGGL(nd_potrf_kernel, dim3(qn, nimg), dim3(BCR_PT), bcr_potrf_lds(HB2_NB), stream, A, k);
+                    hipLaunchKernelGGL(nd_potrf_kernel, dim3(qn, nimg), dim3(BCR_PT), bcr_potrf_lds(std::min(HB2_NB, nd_up16(a.pmax - HB2_NB * k))), stream, A, k);
                     const int below = a.fmax - HB2_NB * k;
                     const int ntile = (below + 63) / 64;
                     if (ntile > 0) hipLaunchKernelGGL(nd_trsm_kernel, dim3(ntile, qn, nimg), dim3(BG_T), 0, stream, A, k);

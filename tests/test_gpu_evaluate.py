@@ -399,8 +399,8 @@ def test_adjoint_split_edge_cases(gpu_solver_cls, oracle, N):
 
 @pytest.mark.parametrize("shape", [(2, 2, 5), (2, 3, 16), (1, 29, 37), (2, 64, 100), (1, 13, 128), (3, 40, 1)])
 def test_both_adjoint_factorisations_agree(gpu_solver_cls, oracle, shape):
-    """The adjoint system is solved by block cyclic reduction (default for M <= 128, N >= 2: level 0 in
-    operator form, dense MFMA levels above) or by the banded Cholesky; both must reproduce the oracle."""
+    """The adjoint system is solved by nested dissection (the default), by block cyclic reduction (M <= 128, N >= 2:
+    level 0 in operator form, dense MFMA levels above) or by the banded Cholesky; all must reproduce the oracle."""
     O, N, M = shape
     ub, f = synth_batch(O, N, M, seed=70 + N + M)
     s = gpu_solver_cls(M, N, O)
@@ -410,7 +410,7 @@ def test_both_adjoint_factorisations_agree(gpu_solver_cls, oracle, shape):
         g0 = oracle.gradient(alpha, u0, ub)
         r0 = oracle.gradient(alpha, u0, ub, reg=True)
         res = {}
-        for meth in ("band", "bcr"):
+        for meth in ("band", "bcr", "nd"):
             _, _, g = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method=meth)
             assert s.stats()["adjoint_method"] == meth
             _, _, r = s.evaluate(alpha, 0.0, maxiter=400, adjoint_method=meth)
@@ -418,9 +418,13 @@ def test_both_adjoint_factorisations_agree(gpu_solver_cls, oracle, shape):
             assert np.allclose(r, r0, rtol=1e-7, atol=1e-11), (meth, shape)
             res[meth] = (np.asarray(g), np.asarray(r))
         assert np.allclose(res["band"][0], res["bcr"][0], rtol=1e-7, atol=1e-11)
-        # the same call twice is bitwise reproducible (no atomics anywhere in the factorisation)
-        _, _, g2 = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method="bcr")
-        assert np.array_equal(np.asarray(g2), res["bcr"][0])
+        assert np.allclose(res["nd"][0], res["bcr"][0], rtol=1e-7, atol=1e-11)
+        # the same call twice is bitwise reproducible (no atomics anywhere in the factorisations)
+        for meth in ("bcr", "nd"):
+            _, _, g2 = s.evaluate(alpha, 0.1, maxiter=400, adjoint_method=meth)
+            assert np.array_equal(np.asarray(g2), res[meth][0])
+        _, _, g3 = s.evaluate(alpha, 0.1, maxiter=400)              # automatic choice
+        assert s.stats()["adjoint_method"] == "nd" and np.array_equal(np.asarray(g3), res["nd"][0])
     s.close()
 
 
@@ -432,8 +436,10 @@ def test_bcr_is_refused_where_it_does_not_apply(gpu_solver_cls):
     with pytest.raises(BpltvError) as e:
         s.evaluate(0.1, 0.1, maxiter=50, adjoint_method="bcr")
     assert e.value.code == 6
-    u, c, g = s.evaluate(0.1, 0.1, maxiter=50)   # automatic choice: banded Cholesky
-    assert np.isfinite(g) and s.stats()["adjoint_method"] == "band"
+    u, c, g = s.evaluate(0.1, 0.1, maxiter=50)   # automatic choice: nested dissection
+    assert np.isfinite(g) and s.stats()["adjoint_method"] == "nd"
+    u, c, g1 = s.evaluate(0.1, 0.1, maxiter=50, adjoint_method="band")
+    assert s.stats()["adjoint_method"] == "band" and np.isclose(g1, g, rtol=1e-7)
     s.close()
 
 

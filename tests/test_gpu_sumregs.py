@@ -42,7 +42,11 @@ def test_evaluate_matches_oracle(gpu_solver_cls, oracle, alpha):
     assert np.shape(grad) == np.shape(g0)
     assert np.allclose(grad, g0, rtol=1e-6, atol=1e-9 * np.abs(g0).max())
     st = s.stats()
-    assert st["adjoint_method"] == "band-hbm" and st["reg_gradient_used"] == 0 and st["adjoint_residual"] <= 1e-8
+    assert st["adjoint_method"] == "nd" and st["reg_gradient_used"] == 0 and st["adjoint_residual"] <= 1e-8
+    # cross-check: the same 13-point system through the HBM band solver at bandwidth 2M
+    _, _, gb = s.sumregs_evaluate(alpha, 0.1, maxiter=1500, adjoint_method="band")
+    assert s.stats()["adjoint_method"] == "band-hbm" and np.allclose(gb, grad, rtol=1e-6, atol=1e-9 * np.abs(g0).max())
+    u, cost, grad = s.sumregs_evaluate(alpha, 0.1, maxiter=1500)
     rows = s.per_image()
     assert rows.shape == (3, 1 + grad.size) and np.allclose(rows.sum(0)[1:], np.ravel(grad), rtol=1e-12)
     if np.ndim(alpha) == 1:     # Delta <= Delta_t = 1e-3: sumregs_gradient_reg (vector parameter)
