@@ -73,6 +73,8 @@ const Variant kVariants[] = {
     VAR(1, 2, 40, 20),  // 11: 40x40 region, 800 threads, 2 px/thread (core 24 at T = 8: 5x5 tiles per 128^2 image)
     VAR(2, 2, 20, 20),  // 12: 40x40 region, 400 threads, 4 px/thread
     VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread   (default for images larger than 256)
+    VAR(3, 2, 32, 32),  // 14: 96x64 region, 1024 threads, 6 px/thread: 150 KB of LDS, redundancy 1.60 at T = 8
+    VAR(2, 3, 48, 16),  // 15: 96x48 region, 768 threads, 6 px/thread: 112 KB of LDS, redundancy 1.80 at T = 8
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
     //  8 x 1024^2 as well: none beats variant 13)
 };
@@ -559,10 +561,17 @@ int compute_gap(bpltv_t* h, double* gap_host /*O or null*/, double* gap_max_host
     const int nblk = 8;
     int rc = ensure(h, &h->d_red, &h->red_cap, (size_t)h->O * nblk * 4);
     if (rc) return rc;
-    const int b = h->result_buf;
-    hipLaunchKernelGGL(gap_partial_kernel, dim3(nblk, h->O), dim3(256), 0, h->stream, h->d_state[b][0],
-                       h->d_state[b][1], h->d_state[b][2], h->d_f, h->d_alpha, h->last_am, h->last_an, h->M,
-                       h->N, h->d_red);
+    if (h->last_is_sr) {   // three-dual model: the seven state planes of the last sum-of-regularisers solve
+        SrState S;
+        for (int c = 0; c < 7; ++c) S.pl[c] = h->d_sr[h->sr_result_buf][c];
+        hipLaunchKernelGGL(sr_gap_partial_kernel, dim3(nblk, h->O), dim3(256), 0, h->stream, S, h->d_f, h->d_alpha, h->last_am,
+                           h->last_an, h->M, h->N, h->d_red);
+    } else {
+        const int b = h->result_buf;
+        hipLaunchKernelGGL(gap_partial_kernel, dim3(nblk, h->O), dim3(256), 0, h->stream, h->d_state[b][0],
+                           h->d_state[b][1], h->d_state[b][2], h->d_f, h->d_alpha, h->last_am, h->last_an, h->M,
+                           h->N, h->d_red);
+    }
     hipLaunchKernelGGL(gap_final_kernel, dim3(1), dim3(256), 0, h->stream, h->d_red, nblk, h->O, h->d_perimg,
                        h->d_scalar);
     HIPCHK(h, hipGetLastError());
@@ -1295,15 +1304,15 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
         h->sr_result_buf = 0; h->sr_has_result = true; h->last_is_sr = true; h->st.pdhg_ms = 0.0;
         return BPLTV_OK;
     }
-    auto enqueue = [&](hipStream_t st) -> int {   // returns the state set holding the result
-        int cur = 0;
-        for (int it = 0; it < p.maxiter; it += T) {
+    // iterations [it0, it1) from the state set `cur`; returns the set holding the result
+    auto enqueue_range = [&](hipStream_t st, int it0, int it1, int cur) -> int {
+        for (int it = it0; it < it1; it += T) {
             SrArgs a;
             const int nxt = (it == 0) ? 0 : 1 - cur;
             for (int c = 0; c < 7; ++c) { a.in[c] = h->d_sr[cur][c]; a.out[c] = h->d_sr[nxt][c]; }
             a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
-            a.it0 = it; a.nit = std::min(T, p.maxiter - it);
+            a.it0 = it; a.nit = std::min(T, it1 - it);
             a.M = M; a.N = N; a.O = h->O; a.nTi = nTi; a.nTj = nTj; a.halo = 2 * T;
             a.first = (it == 0) ? 1 : 0;
             hipLaunchKernelGGL((sr_tile_kernel<SR_R, SR_R>), dim3(grid), dim3(SR_R * SR_R), sr_lds_bytes(SR_R, SR_R), st, a);
@@ -1311,6 +1320,37 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
         }
         return cur;
     };
+    auto enqueue = [&](hipStream_t st) -> int { return enqueue_range(st, 0, p.maxiter, 0); };
+    if (p.check_every > 0) {   // duality-gap checks every check_every iterations, early stop at gap_tol (as the TV model)
+        HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+        int it = 0, cur = 0, launches = 0;
+        h->last_is_sr = true;
+        while (it < p.maxiter) {
+            const int it1 = std::min(p.maxiter, it + p.check_every);
+            cur = enqueue_range(h->stream, it, it1, cur);
+            launches += (it1 - it + T - 1) / T;
+            it = it1;
+            HIPCHK(h, hipGetLastError());
+            h->sr_result_buf = cur;
+            h->sr_has_result = true;
+            double gmax = 0.0;
+            rc = compute_gap(h, nullptr, &gmax);
+            if (rc) return rc;
+            h->st.last_gap = gmax;
+            if (p.gap_tol > 0.0 && gmax <= p.gap_tol) break;
+        }
+        HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms2 = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms2, h->ev[0], h->ev[1]));
+        h->st.pdhg_ms = ms2;
+        h->st.launches = launches;
+        h->st.iterations = it;
+        const bool amap2 = (h->last_am == M && h->last_an == N) && !(M == 1 && N == 1);
+        h->st.bytes_per_px_iter = amap2 ? 144.0 : 120.0;
+        h->st.algorithmic_bytes = h->st.bytes_per_px_iter * (double)h->tot * it;
+        return BPLTV_OK;
+    }
     const int nl = (p.maxiter + T - 1) / T;
     const int buf = (nl - 1) % 2 == 0 ? 0 : 1;   // launch 0 writes set 0, launch l writes set l % 2
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -2197,8 +2237,7 @@ int bpltv_duality_gap(bpltv_t* h, double* gap_out) {
         const int rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_duality_gap(c, gap_out + ms.lo[k]); });
         return rc ? rc : multi_stats(h);
     }
-    if (h->last_is_sr) return set_err(h, BPLTV_E_UNSUPPORTED, "the duality gap is implemented for the TV model only");
-    if (!h->has_result) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
+    if (!(h->last_is_sr ? h->sr_has_result : h->has_result)) return set_err(h, BPLTV_E_NODATA, "no solve has been run yet");
     HIPCHK(h, hipSetDevice(h->device));
     double gmax = 0.0;
     int rc = compute_gap(h, gap_out, &gmax);

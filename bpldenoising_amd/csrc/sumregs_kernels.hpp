@@ -206,6 +206,48 @@ __device__ __forceinline__ double sr_gradT_at(int k, const double* __restrict__ 
     return 0.5 * (a - b) + 0.5 * (c - d);
 }
 
+// Primal-dual gap pieces of the three-dual model per image, the layout of gap_partial_kernel (pdhg_kernels.hpp):
+// partial[(k*nblk+b)*4 + {0: ||u-f||^2, 1: sum_k sum alpha_k |G_k u|, 2: ||f||^2, 3: ||f - K^T y||^2}], K^T y =
+// (G_f^T y_f + G_b^T y_b) + G_c^T y_c; gap_final_kernel turns them into gap_k >= 0.5 ||u_k - u*_k||^2 for every feasible
+// dual.  Checker: bplo_sumregs_gap.  state: the seven planes x, yf1, yf2, yb1, yb2, yc1, yc2.  grid (nblk, O), block 256.
+struct SrState { const double* pl[7]; };
+__global__ __launch_bounds__(256) void sr_gap_partial_kernel(SrState S, const double* __restrict__ f, const double* __restrict__ alpha,
+                                                             int am, int an, int M, int N, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int npx = M * N;
+    const size_t base = (size_t)blockIdx.y * npx;
+    const double* u = S.pl[0] + base;
+    const size_t asl = (size_t)am * an;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < npx; q += gridDim.x * 256) {
+        const int i = q % M, j = q / M;
+        const double uk = u[q], fk = f[base + q];
+        const size_t ai = sr_alpha_index(am, an, M, N, i, j);
+        double w = 0.0, tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double d1, d2;
+            sr_grad_at(k, u, M, N, i, j, d1, d2);
+            tv += alpha[(size_t)k * asl + ai] * sqrt(d1 * d1 + d2 * d2);
+        }
+        w = (sr_gradT_at(0, S.pl[1] + base, S.pl[2] + base, M, N, i, j) + sr_gradT_at(1, S.pl[3] + base, S.pl[4] + base, M, N, i, j)) +
+            sr_gradT_at(2, S.pl[5] + base, S.pl[6] + base, M, N, i, j);
+        const double r = uk - fk;
+        s0 += r * r;
+        s1 += tv;
+        s2 += fk * fk;
+        s3 += (fk - w) * (fk - w);
+    }
+    s0 = block_sum<256>(s0, sh);
+    s1 = block_sum<256>(s1, sh);
+    s2 = block_sum<256>(s2, sh);
+    s3 = block_sum<256>(s3, sh);
+    if (threadIdx.x == 0) {
+        double* p = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3;
+    }
+}
+
 // per element and operator: coefficients of W_k and of the gradient functional; grid over O*M*N, one thread per
 // pixel, all three operators.  reg: gradient_reg (gamma = 1e3 vector / 1e8 patch parameter).
 __global__ __launch_bounds__(256) void sr_adj_setup_kernel(const double* __restrict__ u, const double* __restrict__ ubar,

@@ -134,3 +134,33 @@ def test_sharded_handle(gpu_solver_cls):
     u, c, g = s.sumregs_evaluate(A3, 0.1, maxiter=400, deterministic=1)
     assert np.array_equal(u, u0) and c == c0 and np.array_equal(g, g0)
     s.close()
+
+
+@pytest.mark.parametrize("alpha", [A3, P3], ids=["vector", "patch22"])
+def test_duality_gap_and_early_stop_of_the_three_dual_model(gpu_solver_cls, oracle, alpha):
+    """bpltv_duality_gap after a sum-of-regularisers solve (sr_gap_partial_kernel): the certificate
+    gap_k >= 0.5 ||u_k - u*_k||^2 of the three-dual problem against the oracle's bplo_sumregs_gap; check_every /
+    gap_tol stop the solve as they do for the TV model (reference behaviour = gap_tol 0: fixed count)."""
+    ub, f = synth_batch(3, 48, 40, seed=23)
+    s = gpu_solver_cls(40, 48, 3)
+    s.set_data(ub, f)
+    gaps = []
+    for it in (50, 400, 2000):
+        u = s.sumregs_denoise(alpha, maxiter=it)
+        g = s.duality_gap()
+        u0, y0 = oracle.sumregs_pdhg(f, alpha, maxiter=it, nthreads=4, return_dual=True)
+        assert np.array_equal(u, u0)
+        g0 = oracle.sumregs_gap(u0, y0, f, alpha)
+        assert np.allclose(g, g0, rtol=1e-6, atol=2e-9) and (g >= -1e-10).all()
+        gaps.append(g.max())
+    assert gaps[0] > gaps[1] > gaps[2]
+    # early stop: same iterates as the fixed-count solve of the iteration count it stopped at
+    u = s.sumregs_denoise(alpha, maxiter=4000, check_every=100, gap_tol=float(gaps[1]))
+    st = s.stats()
+    assert st["iterations"] < 4000 and st["iterations"] % 100 == 0 and 0 <= st["last_gap"] <= gaps[1]
+    assert np.array_equal(u, oracle.sumregs_pdhg(f, alpha, maxiter=st["iterations"], nthreads=4))
+    # evaluate with gap checks but no tolerance: the reference's fixed count, same result as without checks
+    _, c1, g1 = s.sumregs_evaluate(alpha, 0.1, maxiter=600, check_every=250)
+    _, c0, g0_ = s.sumregs_evaluate(alpha, 0.1, maxiter=600)
+    assert c1 == c0 and np.array_equal(np.asarray(g1), np.asarray(g0_))
+    s.close()
