@@ -56,6 +56,14 @@ struct NdArgs {
 
 __host__ __device__ inline int nd_up16(int x) { return (x + 15) & ~15; }
 
+#ifdef ND_PROBE_ON   // tools/nd_unit.hip built with -DND_PROBE_ON only: time stamps (100 MHz) of one mid-grid workgroup's phases
+__device__ long long nd_probe_buf[16];
+__device__ int nd_probe_node0 = -1;   // stamp the small-front launch whose first node is this one
+#define ND_PROBE(i) do { if (threadIdx.x == 0 && A.node0 == nd_probe_node0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y - 1) nd_probe_buf[i] = (long long)wall_clock64(); } while (0)
+#else
+#define ND_PROBE(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // small regime
 // ------------------------------------------------------------------------------------------------------------------
@@ -64,8 +72,10 @@ __host__ __device__ inline int nd_up16(int x) { return (x + 15) & ~15; }
 // remaining tiles receive -L21 L21^T.  Layout on exit as bcr_potrf_lds_body's: strictly lower tiles hold L, the
 // pivot block's diagonal and upper tiles hold W = L11^-1 (tile (p, q), q <= p, at tile position (q, p)).
 // dinv: MP doubles of scratch.  Returns true (wave 0) on a non-positive pivot.  NT threads.
-template <int NT>
+// BIG = false: MP <= 64 only (one row per lane in the panel factor: half the registers, twice the workgroups per CU).
+template <int NT, bool BIG>
 __device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP, int Pp, double* __restrict__ dinv) {
+    static_assert(NT >= 128, "a wave for the tile inverses beside the trailing update");
     const int ld = MP + 1, P = MP >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     constexpr int NW = NT / 64;
@@ -90,16 +100,18 @@ __device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP,
             __syncthreads();
         }
         if (wave == 0) {
-            if (MP - 16 * pc > 64) bad |= bcr_panel_factor<true>(S, ld, MP, pc, lane, dinv);
+            if (BIG && MP - 16 * pc > 64) bad |= bcr_panel_factor<true>(S, ld, MP, pc, lane, dinv);
             else bad |= bcr_panel_factor<false>(S, ld, MP, pc, lane, dinv);
         }
         __syncthreads();
     }
-    // trailing tiles (i, j), Pp <= j <= i: -= sum_q L(i, q) L(j, q)^T -- before the inverse overwrites nothing they
-    // read (they read strictly-lower tiles below the pivot block only)
-    {
+    // trailing tiles (i, j), Pp <= j <= i: -= sum_q L(i, q) L(j, q)^T (they read strictly-lower tiles below the pivot
+    // block only), on the waves 1..; meanwhile wave 0 inverts the diagonal tiles of the pivot block (disjoint tiles)
+    if (wave == 0) {
+        for (int t = 0; t < Pp; ++t) bcr_tile_inverse(S + 16 * t + ld * (16 * t), ld, lane, dinv + 16 * t);
+    } else {
         const int m = P - Pp;
-        for (int t = wave; t < m * (m + 1) / 2; t += NW) {
+        for (int t = wave - 1; t < m * (m + 1) / 2; t += NW - 1) {
             int a = 0, c = t;
             while (c > a) { c -= a + 1; ++a; }
             const int i = Pp + a, j = Pp + c;
@@ -118,8 +130,7 @@ __device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP,
             for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)] = acc[g];
         }
     }
-    // W = L11^-1: diagonal tiles, then tile row by tile row (row p needs the rows above it)
-    for (int t = wave; t < Pp; t += NW) bcr_tile_inverse(S + 16 * t + ld * (16 * t), ld, lane, dinv + 16 * t);
+    // W = L11^-1 below the diagonal tiles, tile row by tile row (row p needs the rows above it)
     __syncthreads();
     for (int p = 1; p < Pp; ++p) {
         for (int q = wave; q < p; q += NW) bcr_winv_tile(S, ld, p, q, lr, lk);
@@ -132,61 +143,96 @@ constexpr int NDS_T = 256;
 inline size_t nd_small_lds(int MP) { return sizeof(double) * ((size_t)(MP + 1) * MP + MP); }
 
 // One workgroup per (front, image).  grid (nodes of the batch, nimg), block NDS_T, dynamic LDS nd_small_lds(MPmax).
-__global__ __launch_bounds__(NDS_T) void nd_front_small_kernel(NdArgs A) {
+// Loops over matrix entries run column by column -- a wave per column, lanes along the rows -- so that global
+// accesses are unit-stride and no index needs a division; the children's maps are staged in LDS once.
+// NT = 128 for the smallest fronts (MP <= 48): two waves per front, twice the fronts per CU.
+template <bool BIG, int NT>
+__global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_kernel(NdArgs A) {
     extern __shared__ double S[];
-    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    __shared__ int cmL[2][128];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = NT / 64;
+    ND_PROBE(0);
     const NdNodeDev v = A.nodes[node];
     const int p = v.p, b = v.b, f = p + b, p16 = nd_up16(p), sh = p16 - p;
     const int MP = nd_up16(p16 + b), ld = MP + 1, Pp = p16 >> 4;
     double* dinv = S + (size_t)ld * MP;
-    for (int e = tid; e < ld * MP + MP; e += NDS_T) S[e] = 0.0;
+    // children: descriptors and maps are requested now, they land while the front is cleared
+    NdNodeDev ch[2];
+    int bc[2] = {0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn >= 0) { ch[ci] = A.nodes[cn]; bc[ci] = ch[ci].b; }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+        for (int k = tid; k < bc[ci]; k += NT) {
+            const int R = A.cmap[ch[ci].cmap_off + k];
+            cmL[ci][k] = R < p ? R : R + sh;
+        }
+    for (int e = tid; e < ld * MP + MP; e += NT) S[e] = 0.0;
     __syncthreads();
-    for (int k = p + tid; k < p16; k += NDS_T) S[k + ld * k] = 1.0;   // identity padding of the pivot block
+    ND_PROBE(1);
+    for (int k = p + tid; k < p16; k += NT) S[k + ld * k] = 1.0;   // identity padding of the pivot block
     // matrix entries of this front (unique targets)
     {
         const double* pl = A.planes + (size_t)img * A.n;
-        for (int e = tid; e < v.orig_cnt; e += NDS_T) {
+        for (int e = tid; e < v.orig_cnt; e += NT) {
             const int4 o = A.orig[v.orig_off + e];
             const int r = o.x < p ? o.x : o.x + sh, c = o.y;   // c is a pivot
             S[r + ld * c] += pl[(size_t)o.z * A.tot + o.w];
         }
     }
     __syncthreads();
+    ND_PROBE(2);
     // the children's update matrices, one child after the other (a child's entries hit distinct targets)
     for (int ci = 0; ci < 2; ++ci) {
-        const int cn = ci ? v.child1 : v.child0;
-        if (cn < 0) continue;
-        const NdNodeDev ch = A.nodes[cn];
-        const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
-        const int* cm = A.cmap + ch.cmap_off;
-        const int bc = ch.b;
-        for (int e = tid; e < bc * bc; e += NDS_T) {
-            const int i = e % bc, j = e / bc;
-            if (i < j) continue;
-            int R = cm[i], C = cm[j];
-            R = R < p ? R : R + sh;
-            C = C < p ? C : C + sh;
-            S[R + ld * C] += Uc[e];
+        if (bc[ci] == 0) continue;
+        const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch[ci].u_off;
+        const int n = bc[ci];
+        const int* cm = cmL[ci];
+        for (int j0 = wave; j0 < n; j0 += 4 * NW) {      // four columns per wave and pass: their loads are in flight together
+            double x[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * NW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = j + lane + 64 * h;
+                    x[u][h] = (j < n && i < n) ? Uc[i + (size_t)n * j] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * NW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = j + lane + 64 * h;
+                    if (j < n && i < n) S[cm[i] + ld * cm[j]] += x[u][h];
+                }
+            }
         }
         __syncthreads();
     }
-    const bool bad = nd_partial_potrf<NDS_T>(S, MP, Pp, dinv);
-    if (bad && (tid & 63) == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    ND_PROBE(3);
+    const bool bad = nd_partial_potrf<NT, BIG>(S, MP, Pp, dinv);
+    if (bad && lane == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
     __syncthreads();
+    ND_PROBE(4);
     // factor columns: rows [0, p) = W (zeros above the diagonal), rows [p, f) = L21
     double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
-    for (int e = tid; e < f * p; e += NDS_T) {
-        const int r = e % f, c = e / f;
-        double x;
-        if (r < p) x = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
-        else x = S[(r + sh) + ld * c];
-        fc[e] = x;
-    }
+    for (int c = wave; c < p; c += NW)
+        for (int r = lane; r < f; r += 64) {
+            double x;
+            if (r < p) x = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
+            else x = S[(r + sh) + ld * c];
+            fc[r + (size_t)f * c] = x;
+        }
     double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
-    for (int e = tid; e < b * b; e += NDS_T) {
-        const int i = e % b, j = e / b;
-        if (i >= j) U[e] = S[(p16 + i) + ld * (p16 + j)];
-    }
+    for (int j = wave; j < b; j += NW)
+        for (int i = j + lane; i < b; i += 64) U[i + (size_t)b * j] = S[(p16 + i) + ld * (p16 + j)];
+    ND_PROBE(5);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -218,7 +264,9 @@ __global__ __launch_bounds__(256) void nd_orig_kernel(NdArgs A) {
     }
 }
 
-// extend-add of child `ci` of every front of the level.  grid (blocks, nodes, nimg), block 256.
+// extend-add of child `ci` of every front of the level: a wave per column of the child's update matrix (columns dealt
+// round-robin over the waves of the launch), lanes along its rows -- unit-stride reads, no index arithmetic beyond the
+// two map look-ups.  grid (blocks, nodes, nimg), block 256.
 __global__ __launch_bounds__(256) void nd_extadd_kernel(NdArgs A, int ci) {
     const int node = A.node0 + blockIdx.y, img = blockIdx.z;
     const NdNodeDev v = A.nodes[node];
@@ -230,15 +278,24 @@ __global__ __launch_bounds__(256) void nd_extadd_kernel(NdArgs A, int ci) {
     double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
     const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
     const int* cm = A.cmap + ch.cmap_off;
-    // column j of the child by one thread row each: consecutive threads read consecutive rows
-    const long long cnt = (long long)bc * bc;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (long long)gridDim.x * 256) {
-        const int j = (int)(e / bc), i = (int)(e - (long long)j * bc);
-        if (i < j) continue;
-        const int R = cm[i], C = cm[j];
-        const double x = Uc[e];
-        if (C < p) fc[R + (size_t)f * C] += x;
-        else U[(R - p) + (size_t)b * (C - p)] += x;
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < bc; j += gridDim.x * 4) {
+        const int C = cm[j];
+        double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
+        const double* src = Uc + (size_t)bc * j;
+        for (int i0 = j; i0 < bc; i0 += 256) {     // four row chunks in flight per lane
+            double x[4];
+            int R[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + lane + 64 * u;
+                x[u] = i < bc ? src[i] : 0.0;
+                R[u] = i < bc ? cm[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + lane + 64 * u < bc) dst[R[u]] += x[u];
+        }
     }
 }
 
@@ -287,7 +344,8 @@ __global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
     double* Bs = lds + BG_KC * BG_LD;
     BgAcc acc[2];
     const int nhalf = nb > 64 ? 2 : 1;
-    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // unrolled: the accumulators stay in registers
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[h].c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
         if (h >= nhalf) continue;
@@ -310,7 +368,9 @@ __global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
         }
     }
     const int l = tid & 63, hq = tid >> 6;
-    for (int h = 0; h < nhalf; ++h) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h >= nhalf) continue;
         bg_to_lds(acc[h], lds);      // barriers inside: every read of A by this workgroup has completed before the first write
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {

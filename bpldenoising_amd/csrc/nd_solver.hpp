@@ -98,7 +98,7 @@ struct NdSolver {
         NDCHK(hipMemcpy(d_pix, T.pix.data(), T.pix.size() * sizeof(int), hipMemcpyHostToDevice));
         if (!T.cmap.empty()) NDCHK(hipMemcpy(d_cmap, T.cmap.data(), T.cmap.size() * sizeof(int), hipMemcpyHostToDevice));
         NDCHK(hipMemcpy(d_orig, T.orig.data(), T.orig.size() * sizeof(int4), hipMemcpyHostToDevice));
-        NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_small_kernel<true, NDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)nd_small_lds(128)));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bcr_potrf_lds(HB2_NB)));
@@ -158,7 +158,9 @@ struct NdSolver {
             const int cnt = a.n1 - a.n0;
             if (a.small) {
                 A.node0 = a.n0;
-                hipLaunchKernelGGL(nd_front_small_kernel, dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
+                if (a.MPmax <= 48) hipLaunchKernelGGL((nd_front_small_kernel<false, 128>), dim3(cnt, nimg), dim3(128), nd_small_lds(a.MPmax), stream, A);
+                else if (a.MPmax <= 64) hipLaunchKernelGGL((nd_front_small_kernel<false, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
+                else hipLaunchKernelGGL((nd_front_small_kernel<true, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 continue;
             }
             {
@@ -172,7 +174,7 @@ struct NdSolver {
                 A.node0 = q0;
                 hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, A);
                 if (a.has_child) {
-                    const unsigned gx = (unsigned)std::min<long long>(((long long)a.bcmax * a.bcmax + 2047) / 2048, 512);
+                    const unsigned gx = (unsigned)std::min((a.bcmax + 3) / 4, 128);   // four columns of the child per workgroup pass
                     for (int ci = 0; ci < 2; ++ci)
                         hipLaunchKernelGGL(nd_extadd_kernel, dim3(std::max(1u, gx), qn, nimg), dim3(256), 0, stream, A, ci);
                 }

@@ -150,6 +150,20 @@ static int timing(int M, int nimg, bool sr, int leaf) {
         printf("  rep %d: factor %.2f ms (%.1f TFLOP/s), solve %.2f ms (%.0f GB/s of factor)\n", rep, mf, nimg * S.factor_flop / mf * 1e-9, ms,
                2.0 * nimg * T.fac_doubles * 8 / ms * 1e-6);
     }
+#ifdef ND_PROBE_ON
+    for (int l = T.levels() - 1; l >= 0 && S.lv[l].small; --l) {   // phases of one mid-grid workgroup per small level
+        const int n0 = S.lv[l].n0;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(nd_probe_node0), &n0, sizeof(int)));
+        if (S.factor(d_planes, tot, nimg, d_fail)) return 1;
+        CK(hipStreamSynchronize(stream));
+        long long pb[16];
+        CK(hipMemcpyFromSymbol(pb, HIP_SYMBOL(nd_probe_buf), sizeof(pb)));
+        const NdNode& v = T.nodes[n0 + (S.lv[l].n1 - n0) / 2];
+        printf("  level %2d (%d fronts, p %d b %d): descriptor+zero %.2f us, matrix entries %.2f, children %.2f, factor %.2f, write %.2f, total %.2f\n", l,
+               S.lv[l].n1 - n0, v.p, v.b, (pb[1] - pb[0]) * 0.01, (pb[2] - pb[1]) * 0.01, (pb[3] - pb[2]) * 0.01, (pb[4] - pb[3]) * 0.01, (pb[5] - pb[4]) * 0.01,
+               (pb[5] - pb[0]) * 0.01);
+    }
+#endif
     std::vector<double> x(tot);
     std::vector<int> fail(nimg);
     CK(hipMemcpy(x.data(), d_vec, tot * sizeof(double), hipMemcpyDeviceToHost));
