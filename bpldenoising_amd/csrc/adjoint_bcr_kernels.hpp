@@ -20,7 +20,7 @@
 //   backward p_j = L_j^-T (z_j - XA_j p_a - XB_j p_b)
 // Both orientations of L^-1, XA, XB are stored so that every product reads coalesced columns.
 // Explicit inverses of the (triangular) diagonal factors are accurate enough here because the
-// solve is refined iteratively against the matrix-free operator (tools/bcr_proto.py: the
+// solve is refined iteratively against the matrix-free operator (round-1 numpy prototype: the
 // gradient agrees with the banded solve to 4e-9).
 //
 // Block storage: column major, leading dimension MP; element (r, c) at r + MP*c; block j of image

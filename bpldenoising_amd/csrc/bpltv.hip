@@ -401,7 +401,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     int T = p.tile_iters;
     const bool auto_variant = p.reserved[0] <= 0;
     if (T <= 0 && v == 0) {
-        // Region and fusion depth from a launch-cost model fitted on MI355X (tools/gpu_o1.py, tools/gpu_v128.py):
+        // Region and fusion depth from a launch-cost model fitted on MI355X (round-1 sweeps):
         // a launch costs a fixed ~4.5 us plus T iterations; an iteration of the 32x32 / 1 px kernel takes
         // ~0.47 us while every CU holds at most one workgroup and ~0.94 us per round of two co-resident
         // workgroups beyond that, one of the 48x48 / 3 px kernel 1.36 us resp. 2.1 us.  Deeper fusion means
@@ -428,7 +428,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     }
     const Variant& V = kVariants[v];
     if (T <= 0) {
-        // Large images (tools/gpu_cfg5b.py: 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
+        // Large images (round-1 sweep over 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
         // of 3 px/thread beat the 64x64 / 4 px variant by 7-18 %; depth 8, or 6 once the grid is
         // many times the chip (the smaller halo then saves more arithmetic than the extra launches cost).
         T = 8;
@@ -449,7 +449,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
     // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
     int ch = p.reserved[1];
-    if (ch <= 0) ch = 1;  // with write-through state stores one chain is as fast as two and steadier (tools/gpu_ab.py)
+    if (ch <= 0) ch = 1;  // with write-through state stores one chain is as fast as two and steadier (round-1 A/B)
     if (ch > h->cur_nimg) ch = h->cur_nimg;
     pl->chains = ch;
     return BPLTV_OK;
@@ -1035,7 +1035,7 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
     kact *= kappa_scale;
     // Refinement sweeps: every sweep gains ~2 digits with the 1e14 active-set weight of the scalar gradient and
     // 4-5 digits with the 6.7e7 / 1e8 weights of the patch and regularised gradients, where the second sweep
-    // already reaches rounding level (tools/gpu_refine.py).
+    // already reaches rounding level (round-1 sweep of the refinement count).
     // The HBM band and nested-dissection paths solve with true triangular factors (only 128 x 128 diagonal blocks
     // are inverted): one sweep already reaches the level the block-cyclic-reduction path needs two for
     // (1024^2: pixel map 3.6e-9 / patch 6e-11 / regularised 1e-16 from the converged value after ONE sweep, scalar

@@ -82,7 +82,9 @@ struct NdSolver {
                 for (int ci = 0; ci < 2; ++ci)
                     if (v.child[ci] >= 0) { a.has_child = true; a.bcmax = std::max(a.bcmax, T.nodes[v.child[ci]].b); }
             }
-            a.small = a.MPmax <= 128;
+            // in LDS only while the pivot block is at most three block columns wide: wave 0 factors them one after the
+            // other there; wider pivot blocks (the root of a 128-wide image) go through bcr_potrf_lds_body (large regime)
+            a.small = a.MPmax <= 128 && a.pmax <= 48;
         }
         std::vector<NdNodeDev> nd(T.nodes.size());
         for (size_t q = 0; q < T.nodes.size(); ++q) {

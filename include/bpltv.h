@@ -46,10 +46,13 @@ enum {
     BPLTV_E_NOMEM = 5,
     BPLTV_E_UNSUPPORTED = 6
 };
-/* Sizes: PDHG, loss, sweep and the adjoint gradient accept any M x N x O that fits in HBM.  The gradient
- * factors its linear system by block cyclic reduction for M <= 128 (7*N*MP^2 doubles per image, MP = M
- * rounded up to 16), by a banded Cholesky with an LDS-resident window for M <= 138 and with an
- * HBM-resident band (M*N*(M+1) doubles per image) beyond that; all workspaces are allocated on first use. */
+/* Sizes: PDHG, loss, sweep and the adjoint gradient accept any M x N x O whose images fit in HBM.  The gradient
+ * factors its linear system by a nested-dissection (multifrontal) Cholesky (about 0.9 KB of workspace per pixel:
+ * 0.94 GB for a 1024 x 1024 image); when the workspace of all O images does not fit it runs in groups of as many
+ * images as fit, with bitwise the same result (stats.adjoint_chunks; BPLTV_ADJ_BUDGET_MB forces a budget).
+ * params.reserved[4] selects the cross-check solvers: banded Cholesky (LDS window for M <= 138, HBM-resident band
+ * of M*N*(M+1) doubles per image beyond; whole batch at once) or block cyclic reduction (M <= 128).  All workspaces
+ * are allocated on first use and released again if an allocation fails. */
 
 typedef struct bpltv_handle bpltv_t;
 
@@ -68,9 +71,10 @@ typedef struct bpltv_params {
                             0 = library default for the image size                                */
     int use_graph;       /* 1 (default): replay the launch sequence from a hipGraph               */
     double kappa_cap;    /* cap on the active-set weight 1/eps() of the adjoint system; 0 = 1e14  */
-    int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default (3 for the
-                            scalar gradient, 2 for patch / pixel-map parameters and gradient_reg; on the
-                            HBM band path of wide images 2 / 1 / 0)                               */
+    int refine;          /* iterative-refinement sweeps of the adjoint solve; < 0 = default: 2 / 1 / 0 for the
+                            scalar gradient / patch and pixel-map parameters / gradient_reg with nested
+                            dissection and the HBM band, 3 / 2 / 2 with block cyclic reduction and the
+                            LDS band                                                              */
     int deterministic;   /* multi-GPU handles, scalar / patch parameters: 1 = all-gather the per-image rows
                             [cost_k, grad_k...] and add them in global image order, so that cost and grad are
                             bitwise the same for every number of GPUs (and equal to a single handle's);
@@ -192,8 +196,10 @@ int bpltv_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta
  * am = an = 1 is the Vector x = [a1; a2; a3] (:8), m x n x 3 the patch parameter (:22).  grad_out has the same
  * layout.  p = NULL: bpltv_sumregs_default_params (delta_t = 1e-3).  D > delta_t: sumregs_gradient (:264-407),
  * else sumregs_gradient_reg (:112-262; with a patch parameter its row-scaled system is not symmetric and is
- * factored by a banded LU).  The adjoint system has bandwidth 2M and is factored in HBM for every image size.
- * Both take single- and multi-device handles; set_data, per_image, u_device, stats are shared with the TV model. */
+ * factored by a banded LU).  The adjoint system is a 13-point stencil, factored by nested dissection (separators two
+ * pixels wide; params.reserved[4] = 1: the HBM band solver at bandwidth 2M).
+ * Both take single- and multi-device handles; set_data, per_image, u_device, duality_gap, stats are shared with the TV
+ * model. */
 int bpltv_sumregs_default_params(bpltv_params *p);
 int bpltv_sumregs_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_params *p, double *u_out);
 int bpltv_sumregs_evaluate(bpltv_t *h, const double *alpha, int am, int an, double delta, const bpltv_params *p,
@@ -220,7 +226,8 @@ int bpltv_u_device(bpltv_t *h, const double **d_u);
 /* Copy the last primal result to a device buffer owned by the caller. */
 int bpltv_copy_u_device(bpltv_t *h, double *d_dst);
 
-/* Duality gap of the last solve per image (host, O doubles): gap_k >= 0.5*||u_k - u*_k||^2. */
+/* Duality gap of the last solve per image (host, O doubles): gap_k >= 0.5*||u_k - u*_k||^2.  TV model and
+ * sum-of-regularisers model (the gap of whichever was solved last). */
 int bpltv_duality_gap(bpltv_t *h, double *gap_out);
 
 /* FwdGradientOp and its adjoint on the device (src/TVLearningFunctionVec.jl:17; matrix form

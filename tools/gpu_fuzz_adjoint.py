@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer probe: random shapes through evaluate() against the oracle's gradient -- every adjoint path (block cyclic
-reduction, LDS band, HBM band incl. twisted / odd bandwidth / ragged last panel), both branches, all parameter kinds.
+"""Developer probe: random shapes through evaluate() against the oracle's gradient -- every adjoint path (nested
+dissection = the automatic choice, block cyclic reduction, LDS band, HBM band incl. twisted / odd bandwidth / ragged
+last panel), both branches, all parameter kinds, with and without forced image groups.
 usage: gpu_fuzz_adjoint.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,17 +33,21 @@ for case in range(cases):
         alpha = 0.03 + 0.2 * rng.random((N, M))
     reg = bool(rng.integers(0, 2))
     ub, f = synth_batch(O, N, M, seed=int(rng.integers(1, 10000)))
+    meth = str(rng.choice(["auto", "auto", "band", "bcr" if (M <= 128 and N >= 2) else "nd"]))
+    os.environ.pop("BPLTV_ADJ_BUDGET_MB", None)
+    if meth in ("auto", "nd") and O > 1 and rng.random() < 0.3:
+        os.environ["BPLTV_ADJ_BUDGET_MB"] = "%.3f" % (1.3 * 8e-6 * 40 * M * N * max(4, np.log2(M * N)))   # a group of about one image
     s = TVSolver(M, N, O); s.set_data(ub, f)
     try:
-        u, c, g = s.evaluate(alpha, 0.0 if reg else 0.1, maxiter=300)
+        u, c, g = s.evaluate(alpha, 0.0 if reg else 0.1, maxiter=300, adjoint_method=meth)
         st = s.stats()
         u0 = co.pdhg(f, alpha, maxiter=300)
         g0 = co.gradient(alpha, u0, ub, reg=reg)
         g, g0 = np.asarray(g, dtype=float), np.asarray(g0, dtype=float)
         err = np.abs(g - g0).max() / max(np.abs(g0).max(), 1e-300)
         ok = np.array_equal(u, u0) and err < 1e-4 and st["adjoint_residual"] <= 1e-8
-        print("%s case %2d %-3s O %d N %3d M %3d %-6s reg %d  method %-9s res %.1e  grad err %.1e" % (
-            "ok " if ok else "BAD", case, kind, O, N, M, ak, reg, st["adjoint_method"], st["adjoint_residual"], err), flush=True)
+        print("%s case %2d %-3s O %d N %3d M %3d %-6s reg %d  method %-9s groups %d res %.1e  grad err %.1e" % (
+            "ok " if ok else "BAD", case, kind, O, N, M, ak, reg, st["adjoint_method"], st["adjoint_chunks"], st["adjoint_residual"], err), flush=True)
         bad += not ok
     except Exception as e:
         print("EXC case %d O %d N %d M %d %s reg %d: %s" % (case, O, N, M, ak, reg, e), flush=True)

@@ -1,0 +1,70 @@
+#!/bin/bash
+# Profile recipe of round 3 (run on the GPU box through gpurun; outputs under gpurun_out/prof3/).
+# Same rules as tools/prof2.sh: every rocprofv3 --pmc pass holds counters of ONE budget class (SQ <= 8 per pass,
+# FETCH_SIZE and WRITE_SIZE in passes of their own), the program comes directly after `--`, no trace domain is
+# combined with --pmc.  New this round: the nested-dissection adjoint (tools/_bin/nd_unit and the two evaluate
+# probes) and one counter pass over the HBM band solver's unit binary with event-based stream dependencies
+# (VERDICT r2 item 4 / ADVICE: its log is kept whatever the outcome).
+# usage: tools/prof3.sh [part ...]   parts: bench eval128 evalcfg5 nd hb sumregs   (default: all)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof3
+mkdir -p $OUT
+cd $R
+export TMPDIR=/tmp
+PARTS=${@:-bench eval128 evalcfg5 nd hb sumregs}
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
+SQ2="SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
+kt()  { local tag=$1; shift; echo "== kernel trace $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
+pmc() { local tag=$1; local ctr=$2; shift 2; echo "== pmc $tag: $ctr"; rocprofv3 --pmc $ctr --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
+for part in $PARTS; do
+case $part in
+bench)
+  python3 bench.py --steps 10 --warmup 3 > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
+  tail -1 $OUT/bench.log | cut -c1-300
+  kt kt_bench python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+  ;;
+eval128)
+  python3 tools/eval_once.py > $OUT/eval_128.log 2>&1 || { tail -20 $OUT/eval_128.log; exit 1; }
+  grep -v amdgpu $OUT/eval_128.log
+  kt kt_eval128 python3 tools/eval_once.py
+  pmc pmc_eval128_sq1 "$SQ1" python3 tools/eval_once.py
+  pmc pmc_eval128_sq2 "$SQ2" python3 tools/eval_once.py
+  ;;
+evalcfg5)
+  python3 tools/eval_cfg5.py 8 3 400 > $OUT/eval_cfg5.log 2>&1 || { tail -20 $OUT/eval_cfg5.log; exit 1; }
+  python3 tools/eval_cfg5.py 1 2 400 >> $OUT/eval_cfg5.log 2>&1 || { tail -20 $OUT/eval_cfg5.log; exit 1; }
+  grep -v amdgpu $OUT/eval_cfg5.log
+  kt kt_evalcfg5 python3 tools/eval_cfg5.py 8 1 400
+  pmc pmc_evalcfg5_sq1 "$SQ1" python3 tools/eval_cfg5.py 8 1 40
+  pmc pmc_evalcfg5_sq2 "$SQ2" python3 tools/eval_cfg5.py 8 1 40
+  pmc pmc_evalcfg5_fetch "FETCH_SIZE" python3 tools/eval_cfg5.py 8 1 40
+  pmc pmc_evalcfg5_write "WRITE_SIZE" python3 tools/eval_cfg5.py 8 1 40
+  ;;
+nd)
+  tools/_bin/nd_unit time 1024 8 > $OUT/nd_unit_time.log 2>&1 || { tail $OUT/nd_unit_time.log; exit 1; }
+  tools/_bin/nd_unit time 1024 1 >> $OUT/nd_unit_time.log 2>&1
+  tools/_bin/nd_unit time 128 10 >> $OUT/nd_unit_time.log 2>&1
+  tools/_bin/nd_unit time 128 10 sr >> $OUT/nd_unit_time.log 2>&1
+  cat $OUT/nd_unit_time.log
+  kt kt_nd tools/_bin/nd_unit time 1024 8
+  ;;
+hb)
+  # One counter pass over the HBM band solver's unit binary: a few hundred dispatches, events instead of stream memory
+  # operations (rocprofv3 stalls hipStreamWaitValue32), single stream.  The log stays in gpurun_out/prof3 either way.
+  echo "== pmc hb (lu_unit, BPLTV_HB_SYNC=event, single stream)"
+  export BPLTV_HB_SYNC=event BPLTV_HB_SINGLE_STREAM=1
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_hb_sq -- tools/_bin/lu_unit > $OUT/pmc_hb_sq.log 2>&1
+  echo "rocprofv3 --pmc on lu_unit: exit code $?" | tee -a $OUT/pmc_hb_sq.log
+  tail -3 $OUT/pmc_hb_sq.log
+  python3 tools/refresh_profiles.py aggregate $OUT/pmc_hb_sq
+  unset BPLTV_HB_SYNC BPLTV_HB_SINGLE_STREAM
+  ;;
+sumregs)
+  python3 tools/gpu_sumregs_time.py > $OUT/sumregs_time.log 2>&1 || { tail -20 $OUT/sumregs_time.log; exit 1; }
+  grep -v amdgpu $OUT/sumregs_time.log
+  ;;
+esac
+done
+python3 tools/refresh_profiles.py aggregate $OUT
+du -sh $OUT

@@ -5,7 +5,7 @@
         *counter_collection.csv to one row per (kernel, counter) -- dispatches, mean and sum per dispatch -- and
         every *kernel_trace.csv to its *kernel_stats.csv, then delete the raw per-dispatch files (a 40k-launch
         evaluate is ~100 MB of rows; gpurun brings back 64 MiB).
-  refresh_profiles.py publish [tag]      IN THE BUILD CONTAINER: copy the summaries of gpurun_out/prof2/ into
+  refresh_profiles.py publish [tag]      IN THE BUILD CONTAINER: copy the summaries of gpurun_out/$PROF_DIR (default prof2) into
         profiles/<tag>_*.csv and rebuild profiles/traffic.json (HBM bytes and VALU wave-instructions per
         pdhg_tile_kernel launch, per workload) with the gfx950 FETCH_SIZE x2 correction of
         /opt/skills/guides/MI355X_MICROARCH.md (section HBM).
@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRO = os.path.join(ROOT, "profiles")
-SRC = os.path.join(ROOT, "gpurun_out", "prof2")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("PROF_DIR", "prof2"))
 
 
 def short(name):
@@ -103,7 +103,8 @@ def publish(tag):
     os.makedirs(PRO, exist_ok=True)
     copied = []
     for sub, name in (("kt_bench", "kernel_stats_bench"), ("kt_cfg5", "kernel_stats_cfg5_pdhg"),
-                      ("kt_eval128", "kernel_stats_evaluate_128"), ("kt_evalcfg5", "kernel_stats_cfg5_evaluate")):
+                      ("kt_eval128", "kernel_stats_evaluate_128"), ("kt_evalcfg5", "kernel_stats_cfg5_evaluate"),
+                      ("kt_nd", "kernel_stats_nd_unit_1024x8")):
         ks = newest(os.path.join(sub, "**", "*kernel_stats.csv"))
         if ks:
             shutil.copy(ks, os.path.join(PRO, "%s_%s.csv" % (tag, name))); copied.append(name)
@@ -115,7 +116,7 @@ def publish(tag):
                       ("pmc_evalcfg5_sq2", "pmc_sq2_cfg5_evaluate"), ("pmc_evalcfg5_fetch", "pmc_fetch_cfg5_evaluate"),
                       ("pmc_evalcfg5_write", "pmc_write_cfg5_evaluate"), ("pmc_bench_fetch", "pmc_fetch_pdhg"),
                       ("pmc_bench_write", "pmc_write_pdhg"), ("pmc_cfg5_fetch", "pmc_fetch_cfg5_pdhg"),
-                      ("pmc_cfg5_write", "pmc_write_cfg5_pdhg")):
+                      ("pmc_cfg5_write", "pmc_write_cfg5_pdhg"), ("pmc_hb_sq", "pmc_hb_lu_unit")):
         p = newest(os.path.join(sub, "**", "pmc_summary.csv"))
         if p:
             shutil.copy(p, os.path.join(PRO, "%s_%s_summary.csv" % (tag, name))); copied.append(name)
@@ -126,7 +127,7 @@ def publish(tag):
             lines = [l for l in open(p) if l.startswith("{")]
             if lines:
                 open(os.path.join(PRO, "%s_%s.json" % (tag, name)), "w").write(lines[-1]); copied.append(name)
-    for log in ("eval_cfg5.log", "sumregs_time.log"):
+    for log in ("eval_cfg5.log", "sumregs_time.log", "eval_128.log", "nd_unit_time.log", "pmc_hb_sq.log"):
         p = os.path.join(SRC, log)
         if os.path.exists(p):
             with open(os.path.join(PRO, "%s_%s" % (tag, log)), "w") as fh:
