@@ -229,7 +229,10 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
         valu = {"bound": "valu_f64_issue", "wave_instructions_per_launch": valu_instr,
                 "instr_per_computed_px_iter": valu_instr * 64.0 / computed_px_it,
                 "floor_us": floor_us, "frac": floor_us / launch_us, "source": traffic_src,
-                "note": "upper estimate of the issue floor: every VALU instruction priced at the f64 rate"}
+                # v_fma_f64 sustains 59 of the nominal 78.6 TFLOP/s on this part (tools/mfma_bench.hip, 8 independent
+                # chains per lane, 1-4 waves per SIMD): against that measured rate the kernel sits this much higher
+                "frac_of_measured_issue_rate": floor_us / launch_us * (78.6 / 59.0),
+                "note": "upper estimate of the issue floor: every VALU instruction priced at the nominal f64 rate (4 cycles at 2.4 GHz)"}
     measured_hbm_frac = (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None
     return {"bound": "hbm", "bound_note": "contractual: algorithmic bytes (SURVEY 8d: 56/64 B per pixel-iteration) / launch time; "
                                           "the fused kernel touches HBM once per tile_iters iterations, see `binding`",

@@ -44,6 +44,7 @@ struct Variant {
     void (*launch32)(const PdhgArgs&, int grid, hipStream_t);
     const void* func32;
     size_t lds32;
+    int tiles_per_block;   // 1: one workgroup per tile (pdhg_tile_kernel); > 1: that many one-wave tiles per workgroup
 };
 
 template <typename T, int PI, int PJ, int TI, int TJ>
@@ -58,7 +59,17 @@ void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr",                    \
       &launch_variant<float, PI, PJ, TI, TJ>,                                                   \
       reinterpret_cast<const void*>(&pdhg_tile_kernel<float, PI, PJ, TI, TJ>),                  \
-      pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(float)) }
+      pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(float)), 1 }
+// register tiles: one wave per 32 x (2 PJ) region, WPB waves per workgroup (pdhg_wave_kernel)
+template <typename T, int PJ, int WPB>
+void launch_wave_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pdhg_wave_kernel<T, PJ, WPB>), dim3((grid + WPB - 1) / WPB), dim3(64 * WPB), 0, s, a);
+}
+#define VARW(PJ, WPB)                                                                           \
+    { 32, 2 * PJ, 64 * WPB, &launch_wave_variant<double, PJ, WPB>,                              \
+      reinterpret_cast<const void*>(&pdhg_wave_kernel<double, PJ, WPB>), 0, "wave_32x" #PJ "x2",  \
+      &launch_wave_variant<float, PJ, WPB>,                                                     \
+      reinterpret_cast<const void*>(&pdhg_wave_kernel<float, PJ, WPB>), 0, WPB }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
@@ -75,6 +86,9 @@ const Variant kVariants[] = {
     VAR(1, 3, 48, 16),  // 13: 48x48 region, 768 threads, 3 px/thread   (default for images larger than 256)
     VAR(3, 2, 32, 32),  // 14: 96x64 region, 1024 threads, 6 px/thread: 150 KB of LDS, redundancy 1.60 at T = 8
     VAR(2, 3, 48, 16),  // 15: 96x48 region, 768 threads, 6 px/thread: 112 KB of LDS, redundancy 1.80 at T = 8
+    VARW(16, 4),        // 16: register tiles, one wave per 32x32 region (16 px per lane), no LDS, no barriers
+    VARW(8, 4),         // 17: ... per 32x16 region (8 px per lane)
+    VARW(12, 4),        // 18: ... per 32x24 region (12 px per lane)
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
     //  8 x 1024^2 as well: none beats variant 13)
 };
@@ -205,7 +219,8 @@ struct MultiState {
     std::vector<ncclComm_t> comm;                        // ncclCommInitAll; empty when a device repeats
     int maxloc = 0;                                      // largest shard (rows per rank of the all-gather)
     std::vector<double*> d_rows, d_all;                  // all-gather send / receive buffers per shard
-    size_t rows_cap = 0;                                 // doubles per row buffer
+    std::vector<size_t> rows_cap;                        // doubles per row buffer, per shard (a failed allocation on one
+                                                         // shard leaves the others' buffers and capacities consistent)
 };
 
 namespace {
@@ -490,7 +505,8 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             hipKernelNodeParams kp;
             std::memset(&kp, 0, sizeof(kp));
             kp.func = const_cast<void*>(h->dtype == 32 ? V.func32 : V.func);
-            kp.gridDim = dim3(tilesPerImg * (hi - lo));
+            a.ntiles = tilesPerImg * (hi - lo);
+            kp.gridDim = dim3((tilesPerImg * (hi - lo) + V.tiles_per_block - 1) / V.tiles_per_block);
             kp.blockDim = dim3(V.threads);
             kp.sharedMemBytes = (unsigned)(h->dtype == 32 ? V.lds32 : V.lds);
             kp.kernelParams = kargs;
@@ -535,6 +551,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.Odata = h->O; a.astride = h->cur_astride;
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
     a.img0 = 0;
+    a.ntiles = pl.grid;
 #ifdef BPLTV_EXPERIMENTS
     a.dbg = p.reserved[3];
 #endif
@@ -1701,6 +1718,7 @@ int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nsh
     }
     ms->d_rows.assign(n, nullptr);
     ms->d_all.assign(n, nullptr);
+    ms->rows_cap.assign(n, 0);
     h->st.ngpus = (int)distinct.size();
     h->st.shards = n;
     int rc = multi_run(h, [ms, M, N, dtype](int k, bpltv_t*) -> int {
@@ -1796,12 +1814,15 @@ int multi_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta
         if (rccl) {
             const size_t need = (size_t)ms.maxloc * np;
             rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
-                if (ms.rows_cap < need) {
+                if (ms.rows_cap[k] < need) {
                     if (ms.d_rows[k]) (void)hipFree(ms.d_rows[k]);
                     if (ms.d_all[k]) (void)hipFree(ms.d_all[k]);
                     ms.d_rows[k] = ms.d_all[k] = nullptr;
-                    HIPCHK(c, hipMalloc((void**)&ms.d_rows[k], need * sizeof(double)));
-                    HIPCHK(c, hipMalloc((void**)&ms.d_all[k], need * n * sizeof(double)));
+                    ms.rows_cap[k] = 0;
+                    const int arc = alloc_all(c, {{(void**)&ms.d_rows[k], need * sizeof(double)},
+                                                  {(void**)&ms.d_all[k], need * n * sizeof(double)}}, "all-gather buffers");
+                    if (arc) return arc;
+                    ms.rows_cap[k] = need;
                 }
                 hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, c->stream, c->d_perimg,
                                    c->d_red, c->O, (int)P, ms.maxloc, ms.d_rows[k]);
@@ -1809,7 +1830,6 @@ int multi_evaluate(bpltv_t* h, const double* alpha, int am, int an, double delta
                 return BPLTV_OK;
             });
             if (rc) return rc;
-            ms.rows_cap = std::max(ms.rows_cap, need);
             NCCLCHK(h, ncclGroupStart());
             for (int k = 0; k < n; ++k)
                 NCCLCHK(h, ncclAllGather(ms.d_rows[k], ms.d_all[k], need, ncclDouble, ms.comm[k], ms.shard[k]->stream));

@@ -49,6 +49,7 @@ struct PdhgArgs {
     int Odata;  // images in the dataset; image `img` of the solve uses f[img % Odata] and the
                 // parameter block alpha + (img / Odata) * astride (parameter sweeps: K*Odata problems)
     int astride;
+    int ntiles; // tiles of this launch (pdhg_wave_kernel: several tiles per workgroup, the last one may be short)
 #ifdef BPLTV_EXPERIMENTS
     int dbg;    // timing experiments of tools/ builds only (results are wrong): 1 skip state loads, 2 skip
                 // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads.  The product
@@ -128,6 +129,18 @@ __device__ __forceinline__ float rsqrt_nr(float n2) {
     }
     return r;
 }
+// rsqrt_nr split into its seed and its Newton steps (pdhg_wave_kernel interleaves the steps of several pixels)
+__device__ __forceinline__ void rsqrt_nr_seed(double n2, double& r, double& h) {
+    const unsigned long long u = 0x5FE6EB50C7B537A9ull - ((unsigned long long)__double_as_longlong(n2) >> 1);
+    r = __longlong_as_double((long long)u);
+    h = 0.5 * n2;
+}
+__device__ __forceinline__ void rsqrt_nr_seed(float n2, float& r, float& h) {
+    r = __uint_as_float(0x5F375A86u - (__float_as_uint(n2) >> 1));
+    h = 0.5f * n2;
+}
+__host__ __device__ constexpr int rsqrt_nr_steps(double) { return 4; }
+__host__ __device__ constexpr int rsqrt_nr_steps(float) { return 3; }
 __device__ __forceinline__ double pd_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float pd_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -375,6 +388,217 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------
+// pdhg_wave_kernel: the same fused iteration with ONE WAVE PER TILE and the tile in registers -- no LDS, no barrier.
+//
+// Why: pdhg_tile_kernel keeps every wave of a workgroup in the same phase (two s_barrier per iteration), so on large
+// images, where it is bound by f64 issue, only 0.62 of the issue slots do work.  Here a wave
+// owns a 32 x (2 PJ) region by itself: lane l holds column li = l & 31 of the rows half * PJ .. half * PJ + PJ - 1
+// (half = l >> 5), i.e. PJ pixels per lane, PJ independent dependency chains.  Neighbours along j are the lane's own
+// registers (row pj +- 1; the two halves exchange one row per step), neighbours along i are the adjacent lanes.  Waves never wait for each other, so a SIMD's two resident waves overlap one's loads, shuffles and
+// Newton chains with the other's arithmetic.  Arithmetic per pixel is the oracle's, operation for operation
+// (bit-exact, tests/test_gpu_pdhg.py); the adjacent lanes' values come by DPP (wave_shr / wave_shl), the other half's row
+// by one ds_bpermute per step.  The validity front shrinks by one pixel per iteration exactly as in the tile
+// kernel (values at region edges that are not image borders are halo garbage and never written back).
+// grid ceil(ntiles / WPB), block 64 * WPB: WPB independent waves per workgroup.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T pd_shfl(T v, int src) { return __shfl(v, src, 64); }
+// value of the previous / next lane of the wave by DPP (v_mov_b32_dpp wave_shr:1 / wave_shl:1: VALU moves, no LDS
+// crossbar and no wait; lane 0 resp. 63 keeps its own value).  A ds_bpermute per neighbour costs this kernel 2.3x.
+__device__ __forceinline__ int pd_dpp_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int pd_dpp_next(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double pd_lane_prev(double v) {
+    return __hiloint2double(pd_dpp_prev(__double2hiint(v)), pd_dpp_prev(__double2loint(v)));
+}
+__device__ __forceinline__ double pd_lane_next(double v) {
+    return __hiloint2double(pd_dpp_next(__double2hiint(v)), pd_dpp_next(__double2loint(v)));
+}
+__device__ __forceinline__ float pd_lane_prev(float v) { return __int_as_float(pd_dpp_prev(__float_as_int(v))); }
+__device__ __forceinline__ float pd_lane_next(float v) { return __int_as_float(pd_dpp_next(__float_as_int(v))); }
+
+template <typename T, int PJ, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void pdhg_wave_kernel(PdhgArgs A) {
+    constexpr int RI = 32, RJ = 2 * PJ;
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int tile_g = (int)blockIdx.x * WPB + wave;
+    if (tile_g >= A.ntiles) return;      // a whole wave leaves; there is no barrier in this kernel
+    const int tilesPerImg = A.nTi * A.nTj;
+    const int imgl = tile_g / tilesPerImg;
+    const int img = A.img0 + imgl;
+    const int t = tile_g - imgl * tilesPerImg;
+    const int ta = t % A.nTi, tb = t / A.nTi;
+    int oi, ci0, ci1, oj, cj0, cj1;
+    tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
+    tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
+    const int M = A.M, N = A.N;
+    const size_t base = (size_t)img * M * N;
+    const size_t fbase = (size_t)(img % A.Odata) * M * N;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)(img / A.Odata) * A.astride;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const bool first = A.first != 0;
+    const int gi = oi + li, gic = min(gi, M - 1);
+    T x[PJ], y1[PJ], y2[PJ], f[PJ], al[PJ];
+    size_t gidx[PJ];
+    // every global load is issued before the first use
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = min(oj + half * PJ + pj, N - 1);
+        gidx[pj] = (size_t)gic + (size_t)M * gj;
+        size_t ai = 0;
+        if (amode == 2) ai = gidx[pj];
+        else if (amode == 1) ai = ((unsigned)gic * (unsigned)A.am) / (unsigned)M + (size_t)A.am * (((unsigned)gj * (unsigned)A.an) / (unsigned)N);
+        f[pj] = Af[fbase + gidx[pj]];
+        al[pj] = alpha[ai];
+    }
+    if (!first) {
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            x[pj] = Axin[base + gidx[pj]];
+            y1[pj] = Ay1in[base + gidx[pj]];
+            y2[pj] = Ay2in[base + gidx[pj]];
+        }
+    }
+    const bool in_i = gi < M;
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const bool in = in_i && (oj + half * PJ + pj < N);
+        if (first) { x[pj] = f[pj]; y1[pj] = T(0); y2[pj] = T(0); }
+        if (!in) { f[pj] = T(0); x[pj] = T(0); y1[pj] = T(0); y2[pj] = T(0); al[pj] = T(0); }
+    }
+    const T rho = (T)A.rho;
+    // neighbour availability: lane to the right / row below inside the region AND inside the image (else the pixel's
+    // own xbar is used: the forward difference is exactly +0, the Neumann border)
+    const bool has_right = (li < RI - 1) && (gi < M - 1);
+    const bool has_left = li > 0;
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
+    T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    for (int it = 0; it < A.nit; ++it) {
+        const T* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < A.nit) ? it + 1 : it);
+        const T ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        // ---- primal step.  Waves issue in order: the operations of G = 4 pixels are written stage by stage, so that
+        // consecutive instructions are independent and the f64 pipe (4 cycles issue, longer latency) stays fed by the
+        // two waves of a SIMD.
+        constexpr int G = 4;
+        static_assert(PJ % G == 0, "pixels per lane in groups of four");
+        const T y2_other_last = pd_shfl(y2[PJ - 1], lane ^ 32);   // row PJ-1 of the other half (used by half 1, pj = 0)
+        T xb[PJ];
+#pragma unroll
+        for (int g0 = 0; g0 < PJ; g0 += G) {
+            T y1m[G], y2m[G], dv[G], xn[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int pj = g0 + u;
+                y1m[u] = pd_lane_prev(y1[pj]);
+                y2m[u] = (pj > 0) ? y2[pj - 1] : (half ? y2_other_last : T(0));
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) y1m[u] = has_left ? y1m[u] : T(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) { y1m[u] = y1m[u] - y1[g0 + u]; y2m[u] = y2m[u] - y2[g0 + u]; }
+#pragma unroll
+            for (int u = 0; u < G; ++u) dv[u] = y1m[u] + y2m[u];
+#pragma unroll
+            for (int u = 0; u < G; ++u) dv[u] = dv[u] - f[g0 + u];
+#pragma unroll
+            for (int u = 0; u < G; ++u) xn[u] = pd_fma(-tau, dv[u], x[g0 + u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) xn[u] = xn[u] * inv1ptau;
+#pragma unroll
+            for (int u = 0; u < G; ++u) dv[u] = opw * xn[u];
+#pragma unroll
+            for (int u = 0; u < G; ++u) { xb[g0 + u] = pd_fma(-omega, x[g0 + u], dv[u]); x[g0 + u] = xn[u]; }
+        }
+        // ---- dual step
+        const T xb_other_first = pd_shfl(xb[0], lane ^ 32);       // row 0 of the other half (used by half 0, pj = PJ-1)
+        T n2v[PJ];
+        bool any_out = false;
+#pragma unroll
+        for (int g0 = 0; g0 < PJ; g0 += G) {
+            T xp1[G], xpM[G], n1[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int pj = g0 + u;
+                xp1[u] = pd_lane_next(xb[pj]);
+                xpM[u] = (pj < PJ - 1) ? xb[pj + 1] : (half ? xb[pj] : xb_other_first);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int pj = g0 + u, lj = half * PJ + pj;
+                const bool has_down = (lj < RJ - 1) && (oj + lj < N - 1);
+                xp1[u] = has_right ? xp1[u] : xb[pj];
+                xpM[u] = has_down ? xpM[u] : xb[pj];
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) { xp1[u] = xp1[u] - xb[g0 + u]; xpM[u] = xpM[u] - xb[g0 + u]; }
+#pragma unroll
+            for (int u = 0; u < G; ++u) { y1[g0 + u] = pd_fma(sigma, xp1[u], y1[g0 + u]); y2[g0 + u] = pd_fma(sigma, xpM[u], y2[g0 + u]); }
+            if (rho != T(0)) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const T den = T(1) + sigma * rho / al[g0 + u];
+                    y1[g0 + u] = y1[g0 + u] / den;
+                    y2[g0 + u] = y2[g0 + u] / den;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) n1[u] = y1[g0 + u] * y1[g0 + u];
+#pragma unroll
+            for (int u = 0; u < G; ++u) n2v[g0 + u] = pd_fma(y2[g0 + u], y2[g0 + u], n1[u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) any_out |= n2v[g0 + u] > al[g0 + u] * al[g0 + u];
+        }
+        if (any_out) {
+            // The PJ Newton chains of a lane are independent.  They are written step by step ACROSS the pixels and
+            // pinned (empty asm) so that the compiler neither sinks each chain under its pixel's condition -- one
+            // exec-masked block per pixel, 17 dependent operations each with nothing to overlap -- nor re-serialises
+            // them: the f64 pipe then always has PJ independent operations in flight.  Same operations per pixel as
+            // rsqrt_nr (bit-exact).
+            T r[PJ], hh[PJ];
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) rsqrt_nr_seed(n2v[pj], r[pj], hh[pj]);
+#pragma unroll
+            for (int k = 0; k < rsqrt_nr_steps(T(0)); ++k) {
+#pragma unroll
+                for (int pj = 0; pj < PJ; ++pj) {
+                    const T tq = r[pj] * r[pj];
+                    const T w = pd_fma(-hh[pj], tq, T(1.5));
+                    r[pj] = r[pj] * w;
+                }
+#pragma unroll
+                for (int pj = 0; pj < PJ; ++pj) asm volatile("" : "+v"(r[pj]));
+            }
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) {
+                const T a = al[pj];
+                const T v = a * r[pj];
+                const bool outp = n2v[pj] > a * a;
+                y1[pj] = outp ? y1[pj] * v : y1[pj];
+                y2[pj] = outp ? y2[pj] * v : y2[pj];
+            }
+        }
+        tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = oj + half * PJ + pj;
+        if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1) {
+            const size_t idx = base + gi + (size_t)M * gj;
+            __hip_atomic_store(&Axout[idx], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
