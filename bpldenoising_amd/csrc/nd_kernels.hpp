@@ -15,7 +15,7 @@
 //   small  (front padded to 16 fits 128 x 128): one workgroup per (front, image) assembles the front in LDS (matrix
 //          entries + the children's update matrices through cmap), factors its pivot block columns (wave 0 in
 //          registers, bcr_panel_factor), applies them to the rest on the f64 MFMA and writes W, L21, U.
-//   large  the front stays in HBM/L2: scatter kernels assemble it, then per 128-column pivot panel
+//   large  the front stays in HBM/L2: a gather kernel assembles it (each entry written once), then per 128-column pivot panel
 //          nd_potrf_kernel (Cholesky + inverse of the diagonal block in LDS, bcr_potrf_lds_body) ->
 //          nd_trsm_kernel (rows below: x L11^-T, MFMA tiles, in place) -> nd_syrk_kernel (remaining pivot columns),
 //          and one nd_schur_kernel for U with the whole depth p (64 x 64 MFMA tiles).
@@ -35,6 +35,7 @@ struct NdNodeDev {
     int orig_off, orig_cnt;
     int child0, child1;
     long long fac_off, u_off, uv_off;
+    int inv_off, pad_;         // large-regime fronts: inv[inv_off + ci * f + l] = index of front entry l in child ci's boundary, or -1
 };
 
 struct NdArgs {
@@ -42,6 +43,7 @@ struct NdArgs {
     const int* pix;
     const int* cmap;
     const int4* orig;          // (r, c, plane, pixel)
+    const int* inv;            // parent -> child maps of the large-regime fronts (NdNodeDev::inv_off)
     const double* planes;      // assembled diagonals: planes[plane * tot + img * n + pixel]
     size_t tot;
     int n;                     // pixels per image
@@ -238,16 +240,48 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
 // ------------------------------------------------------------------------------------------------------------------
 // large regime: the front lives in HBM -- factor columns (f x p) and the update-matrix slot (b x b)
 // ------------------------------------------------------------------------------------------------------------------
-// zero the factor columns and the update-matrix slots of a level.  grid (blocks, nimg).
-__global__ __launch_bounds__(256) void nd_zero_kernel(double* __restrict__ fac, long long fac_stride, long long fac0, long long fac_len,
-                                                      double* __restrict__ ws, long long ws_stride, long long ws_len) {
-    const int img = blockIdx.y;
-    double* a = fac + (size_t)img * fac_stride + fac0;
-    double* w = ws + (size_t)img * ws_stride;
-    const long long tot = fac_len + ws_len;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
-        if (e < fac_len) a[e] = 0.0;
-        else w[e - fac_len] = 0.0;
+// Assembly of a large front in GATHER form: every entry (R, C), R >= C, of the front -- factor columns and update-matrix
+// slot -- is written exactly once as the sum of the children's update-matrix entries that map to it (child 0, then child
+// 1; zero where neither reaches), through the parent -> child maps `inv`.  No zero pass, no read-modify-write, no
+// atomics; nd_orig_kernel adds the few matrix entries afterwards.  A wave per front column, lanes down the rows: the
+// maps are monotone, so a wave reads runs of consecutive child entries.  grid (blocks, nodes, nimg), block 256.
+__global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    const bool has = v.inv_off >= 0;
+    const int* inv0 = A.inv + (has ? v.inv_off : 0);
+    const int* inv1 = inv0 + f;
+    const double *U0 = nullptr, *U1 = nullptr;
+    int b0 = 0, b1 = 0;
+    if (has && v.child0 >= 0) { const NdNodeDev ch = A.nodes[v.child0]; U0 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b0 = ch.b; }
+    if (has && v.child1 >= 0) { const NdNodeDev ch = A.nodes[v.child1]; U1 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b1 = ch.b; }
+    const int lane = threadIdx.x & 63;
+    for (int C = blockIdx.x * 4 + (threadIdx.x >> 6); C < f; C += gridDim.x * 4) {
+        const int c0 = U0 ? inv0[C] : -1, c1 = U1 ? inv1[C] : -1;
+        double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
+        const double* s0 = c0 >= 0 ? U0 + (size_t)b0 * c0 : nullptr;
+        const double* s1 = c1 >= 0 ? U1 + (size_t)b1 * c1 : nullptr;
+        for (int R0 = C; R0 < f; R0 += 256) {      // four row chunks in flight per lane
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int R = R0 + lane + 64 * u;
+                double acc = 0.0;
+                if (R < f) {
+                    if (s0) { const int a = inv0[R]; if (a >= 0) acc = s0[a]; }
+                    if (s1) { const int a = inv1[R]; if (a >= 0) acc += s1[a]; }
+                }
+                x[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int R = R0 + lane + 64 * u;
+                if (R < f) dst[R] = x[u];
+            }
+        }
     }
 }
 
@@ -261,41 +295,6 @@ __global__ __launch_bounds__(256) void nd_orig_kernel(NdArgs A) {
     for (int e = threadIdx.x; e < v.orig_cnt; e += 256) {
         const int4 o = A.orig[v.orig_off + e];
         fc[o.x + (size_t)f * o.y] += pl[(size_t)o.z * A.tot + o.w];
-    }
-}
-
-// extend-add of child `ci` of every front of the level: a wave per column of the child's update matrix (columns dealt
-// round-robin over the waves of the launch), lanes along its rows -- unit-stride reads, no index arithmetic beyond the
-// two map look-ups.  grid (blocks, nodes, nimg), block 256.
-__global__ __launch_bounds__(256) void nd_extadd_kernel(NdArgs A, int ci) {
-    const int node = A.node0 + blockIdx.y, img = blockIdx.z;
-    const NdNodeDev v = A.nodes[node];
-    const int cn = ci ? v.child1 : v.child0;
-    if (cn < 0) return;
-    const NdNodeDev ch = A.nodes[cn];
-    const int p = v.p, b = v.b, f = p + b, bc = ch.b;
-    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
-    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
-    const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
-    const int* cm = A.cmap + ch.cmap_off;
-    const int lane = threadIdx.x & 63;
-    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < bc; j += gridDim.x * 4) {
-        const int C = cm[j];
-        double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
-        const double* src = Uc + (size_t)bc * j;
-        for (int i0 = j; i0 < bc; i0 += 256) {     // four row chunks in flight per lane
-            double x[4];
-            int R[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + lane + 64 * u;
-                x[u] = i < bc ? src[i] : 0.0;
-                R[u] = i < bc ? cm[i] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i0 + lane + 64 * u < bc) dst[R[u]] += x[u];
-        }
     }
 }
 
@@ -561,7 +560,10 @@ inline size_t nd_large_lds(int fmax) { return sizeof(double) * ((size_t)fmax + 9
 
 // forward: wf = [rhs_p - s_p ; -s_b]; per pivot panel: y_k = W_kk wf_k, then wf[r] -= L(r, panel k) y_k for every row
 // below; update vector = -wf_b.  grid (nodes, nimg), block NDL_T.
-__global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A) {
+// split != 0 (fronts with many boundary rows): only the pivot rows are updated here and the update vector leaves as
+// the children's sums; nd_fwd_rows_kernel adds L21 y afterwards, 128 boundary rows per workgroup -- the b x p block is
+// most of a large front, and one workgroup per front streams it at one CU's bandwidth.
+__global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A, int split) {
     extern __shared__ double sm[];
     const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const NdNodeDev v = A.nodes[node];
@@ -608,16 +610,17 @@ __global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A) {
         }
         __syncthreads();
         // rows below the diagonal block: wf[r] -= sum_c L(r, c0 + c) y[c]; 128 rows x 8 column groups per pass
-        for (int R0 = c0 + nb; R0 < f; R0 += HB2_NB) {
+        const int rend = split ? p : f;
+        for (int R0 = c0 + nb; R0 < rend; R0 += HB2_NB) {
             const int r = R0 + r128;
             double acc = 0.0;
-            if (r < f) {
+            if (r < rend) {
                 const double* Lr = fc + r + (size_t)f * c0;
                 for (int c = g8; c < nb; c += 8) acc = __builtin_fma(Lr[(size_t)f * c], wf[c0 + c], acc);
             }
             part[g8 * HB2_NB + r128] = acc;
             __syncthreads();
-            if (tid < HB2_NB && R0 + tid < f) {
+            if (tid < HB2_NB && R0 + tid < rend) {
                 double s = 0.0;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
@@ -629,9 +632,68 @@ __global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A) {
     for (int i = tid; i < b; i += NDL_T) uvi[v.uv_off + i] = -wf[p + i];
 }
 
+// update vector += L21 y for 128 boundary rows of a front.  grid (ceil(bmax / 128), nodes, nimg), block NDL_T, dynamic
+// LDS (pmax + 8 * 128) doubles.
+__global__ __launch_bounds__(NDL_T) void nd_fwd_rows_kernel(NdSolveArgs A) {
+    extern __shared__ double sm[];
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, i0 = HB2_NB * (int)blockIdx.x;
+    if (i0 >= b) return;
+    double* yp = sm;            // [p]
+    double* part = sm + p;      // [8][128]
+    const int* px = A.pix + v.piv_off;
+    const double* yo = A.y + (size_t)img * A.n;
+    for (int c = tid; c < p; c += NDL_T) yp[c] = yo[px[c]];
+    __syncthreads();
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const int r128 = tid & 127, g8 = tid >> 7, i = i0 + r128;
+    double acc = 0.0;
+    if (i < b) {
+        const double* Lr = fc + (p + i);
+        for (int c = g8; c < p; c += 8) acc = __builtin_fma(Lr[(size_t)f * c], yp[c], acc);
+    }
+    part[g8 * HB2_NB + r128] = acc;
+    __syncthreads();
+    if (tid < HB2_NB && i0 + tid < b) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+        double* uvi = A.uv + (size_t)img * A.uv_stride + v.uv_off;
+        uvi[i0 + tid] += s;
+    }
+}
+
+// y_c -= sum_i L21(i, c) x_b(i) for the 128 columns of one pivot panel (a wave per column, lanes along the rows): the
+// boundary part of the backward step, ahead of nd_bwd_large_kernel(split).  grid (ceil(pmax / 128), nodes, nimg),
+// block NDL_T, dynamic LDS bmax doubles.
+__global__ __launch_bounds__(NDL_T) void nd_bwd_cols_kernel(NdSolveArgs A) {
+    extern __shared__ double sm[];
+    const int node = A.node0 + blockIdx.y, img = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, c0 = HB2_NB * (int)blockIdx.x;
+    if (c0 >= p) return;
+    const int* px = A.pix + v.piv_off;
+    const double* x = A.vec + (size_t)img * A.n;
+    double* yo = A.y + (size_t)img * A.n;
+    for (int i = tid; i < b; i += NDL_T) sm[i] = x[px[p + i]];
+    __syncthreads();
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const int nb = min(HB2_NB, p - c0);
+    for (int c = wave; c < nb; c += NDL_T / 64) {
+        const double* col = fc + p + (size_t)f * (c0 + c);
+        double acc = 0.0;
+        for (int i = lane; i < b; i += 64) acc = __builtin_fma(col[i], sm[i], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) yo[px[c0 + c]] -= acc;
+    }
+}
+
 // backward: vf = [x_p ; x_b]; panels from the last to the first: t_c = y_c - sum_{r below the block} L(r, c) vf[r]
 // (a wave per column, lanes along the rows), x_k = W_kk^T t.  grid (nodes, nimg), block NDL_T.
-__global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A) {
+// split != 0: the boundary rows have been applied by nd_bwd_cols_kernel; only the pivot rows are swept here.
+__global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A, int split) {
     extern __shared__ double sm[];
     const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const NdNodeDev v = A.nodes[node];
@@ -642,17 +704,19 @@ __global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A) {
     const int* px = A.pix + v.piv_off;
     double* x = A.vec + (size_t)img * A.n;
     const double* yo = A.y + (size_t)img * A.n;
-    for (int i = tid; i < b; i += NDL_T) vf[p + i] = x[px[p + i]];
+    if (!split)
+        for (int i = tid; i < b; i += NDL_T) vf[p + i] = x[px[p + i]];
     __syncthreads();
     const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
     double* ac = A.acc ? A.acc + (size_t)img * A.n : nullptr;
     const int npan = (p + HB2_NB - 1) / HB2_NB;
+    const int rend = split ? p : f;
     for (int k = npan - 1; k >= 0; --k) {
         const int c0 = HB2_NB * k, nb = min(HB2_NB, p - c0), rlo = c0 + nb;
         for (int c = wave; c < nb; c += NDL_T / 64) {
             const double* col = fc + (size_t)f * (c0 + c);
             double acc = 0.0;
-            for (int r = rlo + lane; r < f; r += 64) acc = __builtin_fma(col[r], vf[r], acc);
+            for (int r = rlo + lane; r < rend; r += 64) acc = __builtin_fma(col[r], vf[r], acc);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
             if (lane == 0) tt[c] = yo[px[c0 + c]] - acc;

@@ -31,7 +31,7 @@ struct NdSolver {
     bool built = false;
     int cap = 0;                       // images the workspace holds
     NdNodeDev* d_nodes = nullptr;
-    int *d_pix = nullptr, *d_cmap = nullptr;
+    int *d_pix = nullptr, *d_cmap = nullptr, *d_inv = nullptr;
     int4* d_orig = nullptr;
     double *fac = nullptr, *ws[2] = {nullptr, nullptr}, *yv = nullptr, *uv = nullptr;
     hipStream_t stream = nullptr;
@@ -89,13 +89,33 @@ struct NdSolver {
         std::vector<NdNodeDev> nd(T.nodes.size());
         for (size_t q = 0; q < T.nodes.size(); ++q) {
             const NdNode& v = T.nodes[q];
-            nd[q] = NdNodeDev{v.p, v.b, v.piv_off, v.cmap_off, v.orig_off, v.orig_cnt, v.child[0], v.child[1], v.fac_off, v.u_off, v.uv_off};
+            nd[q] = NdNodeDev{v.p, v.b, v.piv_off, v.cmap_off, v.orig_off, v.orig_cnt, v.child[0], v.child[1], v.fac_off, v.u_off, v.uv_off, -1, 0};
+        }
+        // parent -> child maps of the large-regime fronts (gather-form assembly, nd_gather_kernel)
+        std::vector<int> inv;
+        for (int l = 0; l < L; ++l) {
+            if (lv[l].small) continue;
+            for (int q = lv[l].n0; q < lv[l].n1; ++q) {
+                const NdNode& v = T.nodes[q];
+                if (v.child[0] < 0 && v.child[1] < 0) continue;
+                const int f = v.p + v.b;
+                nd[q].inv_off = (int)inv.size();
+                inv.resize(inv.size() + 2 * (size_t)f, -1);
+                for (int ci = 0; ci < 2; ++ci) {
+                    if (v.child[ci] < 0) continue;
+                    const NdNode& ch = T.nodes[v.child[ci]];
+                    int* dst = inv.data() + nd[q].inv_off + (size_t)ci * f;
+                    for (int k = 0; k < ch.b; ++k) dst[T.cmap[ch.cmap_off + k]] = k;
+                }
+            }
         }
         static_assert(sizeof(NdOrig) == sizeof(int4), "NdOrig is uploaded as int4");
         NDCHK(hipMalloc((void**)&d_nodes, nd.size() * sizeof(NdNodeDev)));
         NDCHK(hipMalloc((void**)&d_pix, std::max<size_t>(1, T.pix.size()) * sizeof(int)));
         NDCHK(hipMalloc((void**)&d_cmap, std::max<size_t>(1, T.cmap.size()) * sizeof(int)));
         NDCHK(hipMalloc((void**)&d_orig, std::max<size_t>(1, T.orig.size()) * sizeof(int4)));
+        NDCHK(hipMalloc((void**)&d_inv, std::max<size_t>(1, inv.size()) * sizeof(int)));
+        if (!inv.empty()) NDCHK(hipMemcpy(d_inv, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice));
         NDCHK(hipMemcpy(d_nodes, nd.data(), nd.size() * sizeof(NdNodeDev), hipMemcpyHostToDevice));
         NDCHK(hipMemcpy(d_pix, T.pix.data(), T.pix.size() * sizeof(int), hipMemcpyHostToDevice));
         if (!T.cmap.empty()) NDCHK(hipMemcpy(d_cmap, T.cmap.data(), T.cmap.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -138,9 +158,9 @@ struct NdSolver {
     }
     void release() {
         free_ws();
-        for (void* p : {(void*)d_nodes, (void*)d_pix, (void*)d_cmap, (void*)d_orig})
+        for (void* p : {(void*)d_nodes, (void*)d_pix, (void*)d_cmap, (void*)d_orig, (void*)d_inv})
             if (p) (void)hipFree(p);
-        d_nodes = nullptr; d_pix = d_cmap = nullptr; d_orig = nullptr;
+        d_nodes = nullptr; d_pix = d_cmap = d_inv = nullptr; d_orig = nullptr;
         built = false;
     }
 
@@ -149,7 +169,7 @@ struct NdSolver {
     int factor(const double* planes, size_t tot, int nimg, int* d_fail) {
         if (!built || nimg > cap) { err = "nd solver: not built or workspace too small"; return 2; }
         NdArgs A;
-        A.nodes = d_nodes; A.pix = d_pix; A.cmap = d_cmap; A.orig = d_orig;
+        A.nodes = d_nodes; A.pix = d_pix; A.cmap = d_cmap; A.orig = d_orig; A.inv = d_inv;
         A.planes = planes; A.tot = tot; A.n = T.n;
         A.fac = fac; A.fac_stride = T.fac_doubles; A.fail = d_fail;
         const int L = T.levels();
@@ -165,21 +185,11 @@ struct NdSolver {
                 else hipLaunchKernelGGL((nd_front_small_kernel<true, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 continue;
             }
-            {
-                const long long tot_z = a.fac_len + a.ws_len;
-                const unsigned nb = (unsigned)std::min<long long>((tot_z + 2047) / 2048, 4096);
-                hipLaunchKernelGGL(nd_zero_kernel, dim3(nb, nimg), dim3(256), 0, stream, fac, (long long)T.fac_doubles, a.fac0, a.fac_len,
-                                   ws[l & 1], (long long)T.ws_doubles[l & 1], a.ws_len);
-            }
             for (int q0 = a.n0; q0 < a.n1; q0 += 32768) {     // grid.y <= 65535
                 const int qn = std::min(32768, a.n1 - q0);
                 A.node0 = q0;
+                hipLaunchKernelGGL(nd_gather_kernel, dim3(std::max(1, std::min((a.fmax + 3) / 4, 128)), qn, nimg), dim3(256), 0, stream, A);
                 hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, A);
-                if (a.has_child) {
-                    const unsigned gx = (unsigned)std::min((a.bcmax + 3) / 4, 128);   // four columns of the child per workgroup pass
-                    for (int ci = 0; ci < 2; ++ci)
-                        hipLaunchKernelGGL(nd_extadd_kernel, dim3(std::max(1u, gx), qn, nimg), dim3(256), 0, stream, A, ci);
-                }
                 const int npan = (a.pmax + HB2_NB - 1) / HB2_NB;
                 for (int k = 0; k < npan; ++k) {
                     hipLaunchKernelGGL(nd_potrf_kernel, dim3(qn, nimg), dim3(BCR_PT), bcr_potrf_lds(std::min(HB2_NB, nd_up16(a.pmax - HB2_NB * k))), stream, A, k);
@@ -210,21 +220,33 @@ struct NdSolver {
         const int L = T.levels();
         for (int l = L - 1; l >= 0; --l) {
             const Level& a = lv[l];
-            for (int q0 = a.n0; q0 < a.n1; q0 += 1 << 20) {
+            for (int q0 = a.n0; q0 < a.n1; q0 += (a.small ? 1 << 20 : 32768)) {
                 S.node0 = q0;
-                const int qn = std::min(1 << 20, a.n1 - q0);
+                const int qn = std::min(a.small ? 1 << 20 : 32768, a.n1 - q0);
                 if (a.small) hipLaunchKernelGGL(nd_fwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
-                else hipLaunchKernelGGL(nd_fwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S);
+                else {
+                    const int split = a.bmax >= 256 ? 1 : 0;   // many boundary rows: L21 y by row blocks, behind the pivot sweep
+                    hipLaunchKernelGGL(nd_fwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S, split);
+                    if (split)
+                        hipLaunchKernelGGL(nd_fwd_rows_kernel, dim3((a.bmax + HB2_NB - 1) / HB2_NB, qn, nimg), dim3(NDL_T),
+                                           sizeof(double) * ((size_t)a.pmax + 8 * HB2_NB), stream, S);
+                }
             }
         }
         S.acc = acc;
         for (int l = 0; l < L; ++l) {
             const Level& a = lv[l];
-            for (int q0 = a.n0; q0 < a.n1; q0 += 1 << 20) {
+            for (int q0 = a.n0; q0 < a.n1; q0 += (a.small ? 1 << 20 : 32768)) {
                 S.node0 = q0;
-                const int qn = std::min(1 << 20, a.n1 - q0);
+                const int qn = std::min(a.small ? 1 << 20 : 32768, a.n1 - q0);
                 if (a.small) hipLaunchKernelGGL(nd_bwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
-                else hipLaunchKernelGGL(nd_bwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S);
+                else {
+                    const int split = a.bmax >= 256 ? 1 : 0;
+                    if (split)
+                        hipLaunchKernelGGL(nd_bwd_cols_kernel, dim3((a.pmax + HB2_NB - 1) / HB2_NB, qn, nimg), dim3(NDL_T),
+                                           sizeof(double) * ((size_t)a.bmax + 64), stream, S);
+                    hipLaunchKernelGGL(nd_bwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S, split);
+                }
             }
         }
         NDCHK(hipGetLastError());
