@@ -164,7 +164,10 @@ int bpltv_create(bpltv_t **h, int M, int N, int O, int device, int dtype);
  * doubles): ncclAllReduce(sum, f64), or ncclAllGather of the per-image rows when params.deterministic.
  * set_data / denoise / evaluate / gradient / sweep / per_image / duality_gap take and return whole-batch
  * host arrays exactly as with bpltv_create (each device copies its slice); the device-pointer entry points
- * (set_data_device, evaluate_device, u_device, copy_u_device) return BPLTV_E_UNSUPPORTED on more than one shard. */
+ * (set_data_device, evaluate_device, u_device, copy_u_device) return BPLTV_E_UNSUPPORTED on more than one shard.
+ * Status: verified with ngpus = 1 (a one-rank communicator) and with several shards on one device (host sum); the
+ * collectives over ngpus > 1 have not yet run on hardware -- tests/test_gpu_multi.py holds the checks that switch on
+ * when two or more devices are visible.  stats.nccl_ranks reports what ncclCommCount says. */
 int bpltv_create_multi(bpltv_t **h, int M, int N, int O, int ngpus, int dtype);
 /* Explicit placement: shard k of `nshards` runs on HIP device devices[k].  A device may appear more than
  * once (rehearsal of the sharded path on one GPU); RCCL cannot put two ranks on one device, so the collective
