@@ -14,8 +14,9 @@
 // iterations while HBM/L2 sees the state once: algorithmic traffic 56 B/px/iter (64 with an alpha
 // map), actual traffic ~ (4 reads * (1+halo overhead) + 3 writes) * 8 B / nit.  State is
 // ping-ponged between two buffer sets because neighbouring tiles read each other's halos.
-// Pixel -> thread map is interleaved (li = ti + TI*pi) so that a wave's LDS and global accesses
-// are unit-stride (conflict-free ds_read_b64, coalesced 512 B global rows).
+// Pixel -> thread map: interleaved along i (li = ti + TI*pi) so that a wave's LDS and global accesses
+// are unit-stride (conflict-free ds_read_b64, coalesced 512 B global rows); consecutive along j (lj = PJ*tj + pj), so
+// that a wave owns a block of whole, adjacent rows -- the rows of the halo can then stop early (below).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const int li = ti + TI * pi, lj = PJ * tj + pj;
             const int gi = min(oi + li, M - 1), gj = min(oj + lj, N - 1);
             gidx[pj][pi] = base + gi + (size_t)M * gj;
             fidx[pj][pi] = fbase + gi + (size_t)M * gj;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const int li = ti + TI * pi, lj = PJ * tj + pj;
             const bool in = (oi + li < M) && (oj + lj < N);
             if (first) {
                 x[pj][pi] = f[pj][pi];
@@ -264,26 +265,42 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const int li = ti + TI * pi, lj = PJ * tj + pj;
             const int l = lj * RI + li;
             n1[pj][pi] = l + (((oi + li) < M - 1) ? 1 : 0);
             n2[pj][pi] = l + (((oj + lj) < N - 1) ? RI : 0);
         }
+    // Halo rows do not need all the iterations.  The validity front moves in by one row per iteration: a row k rows
+    // away from a region edge that is not an image border is only ever read for what it held after k iterations (k + 1
+    // primal steps at the far edge, where the dual of the row above still reads its xbar); what it computes later is
+    // garbage nobody uses.  A wave whose rows are all past their use stops computing and only keeps the barriers
+    // company.  Enabled for the multi-pixel variants of the large images, where the loop is bound by f64 issue (the
+    // freed slots go to the co-resident workgroup); with one pixel per thread -- the small batches, bound by the
+    // latency of the computing waves' dependent chain -- it was measured to buy nothing.
+    int my_nit = nit;
+    if (PI * PJ > 1 && N > RJ) {
+        const int w0 = (tid & ~63) / TI, w1 = min((tid | 63) / TI, TJ - 1);      // thread rows of this wave
+        const int r0 = PJ * w0, r1 = PJ * w1 + PJ - 1;                          // pixel rows of this wave
+        if (oj > 0) my_nit = min(my_nit, r1);                                   // near edge: row k needs k iterations
+        if (oj + RJ < N) my_nit = min(my_nit, RJ - r0);                         // far edge: row k' rows from it needs k' + 1
+    }
     // step sizes of iteration `it`: scalar loads, issued one iteration ahead
     const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
     T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
     for (int it = 0; it < nit; ++it) {
         const T* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
         const T ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        const bool act = it < my_nit;
         T xb[PJ][PI];
         // ---- primal step: x <- prox_{tau*fidelity}(x - tau * G^T y); over-relaxation.
         // LDS reads are unconditional (clamped index) and selected afterwards: one wait for all.
         T y1m[PJ][PI], y2m[PJ][PI];
+        if (act) {
 #pragma unroll
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                const int li = ti + TI * pi, lj = PJ * tj + pj;
                 y1m[pj][pi] = sy1[lj * S1 + li];        // (li-1)+1: guard column at li = 0
                 y2m[pj][pi] = sy2[lj * RI + li];        // (lj-1)+1: guard row at lj = 0
             }
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                const int li = ti + TI * pi, lj = PJ * tj + pj;
                 const int l = lj * RI + li;
                 const T div = (y1m[pj][pi] - y1[pj][pi]) + (y2m[pj][pi] - y2[pj][pi]);
                 const T tt = div - f[pj][pi];
@@ -302,7 +319,9 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
                 xb[pj][pi] = b;
                 sxb[l] = b;
             }
+        }
         __syncthreads();
+        if (act) {
         // ---- dual step: y <- proj_{|y_ij| <= alpha_ij}((y + sigma * G xbar) / (1 + sigma*rho/alpha))
         T xp1[PJ][PI], xpM[PJ][PI];
 #pragma unroll
@@ -353,10 +372,11 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
             for (int pi = 0; pi < PI; ++pi) {
-                const int li = ti + TI * pi, lj = tj + TJ * pj;
+                const int li = ti + TI * pi, lj = PJ * tj + pj;
                 sy1[lj * S1 + li + 1] = y1[pj][pi];
                 sy2[(lj + 1) * RI + li] = y2[pj][pi];
             }
+        }
         tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
         __syncthreads();
     }
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
     for (int pj = 0; pj < PJ; ++pj)
 #pragma unroll
         for (int pi = 0; pi < PI; ++pi) {
-            const int li = ti + TI * pi, lj = tj + TJ * pj;
+            const int li = ti + TI * pi, lj = PJ * tj + pj;
             const int gi = oi + li, gj = oj + lj;
             if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1 && !(BPLTV_DBG(A) & 2)) {
                 const size_t idx = base + gi + (size_t)M * gj;
