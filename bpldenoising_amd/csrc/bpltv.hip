@@ -89,6 +89,8 @@ const Variant kVariants[] = {
     VARW(16, 4),        // 16: register tiles, one wave per 32x32 region (16 px per lane), no LDS, no barriers
     VARW(8, 4),         // 17: ... per 32x16 region (8 px per lane)
     VARW(12, 4),        // 18: ... per 32x24 region (12 px per lane)
+    // (64x36 / 3 px and 64x48 / 4 px with 64-thread rows -- whole halo waves that stop early -- were measured too: 86
+    //  resp. 110 VGPRs, one workgroup per CU, 1.88e4 / 2.14e4 it/s on 8 x 1024^2 against 2.55e4 for variant 13)
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
     //  8 x 1024^2 as well: none beats variant 13)
 };
