@@ -150,9 +150,11 @@ __device__ __forceinline__ void bcr_winv_tile(double* __restrict__ S, int ld, in
 // Block column p (16 columns, rows 16p .. MP-1, already updated with the columns to its left) of the matrix in S,
 // factored by one wave in registers: lane l holds row 16p + l (and row 16p + 64 + l when TWO: more than 64 rows).
 // Writes L back (zeros above the diagonal of the diagonal tile) and 1 / L(r, r) to dinv.
+// nact < 16: only the first nact columns of the block column are real, the others are identity padding (the fronts of
+// the nested-dissection solver pad their pivot block to 16): their pivot chains are skipped.
 template <bool TWO>
 __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld, int MP, int p, int lane,
-                                                 double* __restrict__ dinv) {
+                                                 double* __restrict__ dinv, int nact = 16) {
     const int r0 = 16 * p + lane, r1 = r0 + 64;
     const bool v0 = r0 < MP, v1 = TWO && r1 < MP;
     double m0[16], m1[16], dv[16], dd[16];
@@ -169,6 +171,10 @@ __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld,
     // 2.5 us against 2.0 us per block column; the wait for the store sits on the chain.)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
+        if (q >= nact) {   // identity column: pivot 1, nothing to eliminate (wave-uniform)
+            dd[q] = 1.0; dv[q] = 1.0;
+            continue;
+        }
         if (q > 0) {
             const double l = readlane_f64(m0[q - 1], q);
             m0[q] = __builtin_fma(-m0[q - 1], l, m0[q]);
@@ -176,7 +182,7 @@ __device__ __forceinline__ bool bcr_panel_factor(double* __restrict__ S, int ld,
         const double piv = readlane_f64(m0[q], q);
         if (!(piv > 0.0)) bad = true;
         sqrt_rsqrt(piv, dd[q], dv[q]);
-        if (q + 1 < 16) {
+        if (q + 1 < 16 && q + 1 < nact) {
 #pragma unroll
             for (int c = 0; c < q; ++c) {
                 const double l = readlane_f64(m0[c], q + 1);

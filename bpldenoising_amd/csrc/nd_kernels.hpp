@@ -75,8 +75,9 @@ __device__ int nd_probe_node0 = -1;   // stamp the small-front launch whose firs
 // pivot block's diagonal and upper tiles hold W = L11^-1 (tile (p, q), q <= p, at tile position (q, p)).
 // dinv: MP doubles of scratch.  Returns true (wave 0) on a non-positive pivot.  NT threads.
 // BIG = false: MP <= 64 only (one row per lane in the panel factor: half the registers, twice the workgroups per CU).
+// pact: real pivots (<= 16 Pp); the rest of the last block column is identity padding and is skipped by the panel factor.
 template <int NT, bool BIG>
-__device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP, int Pp, double* __restrict__ dinv) {
+__device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP, int Pp, double* __restrict__ dinv, int pact) {
     static_assert(NT >= 128, "a wave for the tile inverses beside the trailing update");
     const int ld = MP + 1, P = MP >> 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -102,8 +103,9 @@ __device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP,
             __syncthreads();
         }
         if (wave == 0) {
-            if (BIG && MP - 16 * pc > 64) bad |= bcr_panel_factor<true>(S, ld, MP, pc, lane, dinv);
-            else bad |= bcr_panel_factor<false>(S, ld, MP, pc, lane, dinv);
+            const int nact = min(16, pact - 16 * pc);
+            if (BIG && MP - 16 * pc > 64) bad |= bcr_panel_factor<true>(S, ld, MP, pc, lane, dinv, nact);
+            else bad |= bcr_panel_factor<false>(S, ld, MP, pc, lane, dinv, nact);
         }
         __syncthreads();
     }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
         __syncthreads();
     }
     ND_PROBE(3);
-    const bool bad = nd_partial_potrf<NT, BIG>(S, MP, Pp, dinv);
+    const bool bad = nd_partial_potrf<NT, BIG>(S, MP, Pp, dinv, p);
     if (bad && lane == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
     __syncthreads();
     ND_PROBE(4);
