@@ -828,7 +828,7 @@ int adj_group(bpltv_t* h, size_t per_image, size_t held, const char* what, int* 
     if (g < 1)
         return set_err(h, BPLTV_E_NOMEM, "adjoint gradient (%s): the factor workspace of ONE %dx%d image needs %.2f GB of HBM, %.2f GB available",
                        what, h->M, h->N, per_image / 1e9, budget / 1e9);
-    *Oc = (int)std::min<size_t>(g, (size_t)h->O);
+    *Oc = (int)std::min<size_t>(std::min<size_t>(g, (size_t)h->O), 32768);   // images are a grid dimension of the solver kernels
     return BPLTV_OK;
 }
 
