@@ -122,11 +122,12 @@ struct TabKey {
 };
 
 struct SrGraphKey {
-    int maxiter, T, am, an, accel;
+    int maxiter, T, am, an, accel, variant;
     double rho, tau0, sigma0;
     const void* tab;
     bool operator<(const SrGraphKey& o) const {
-        return std::tie(maxiter, T, am, an, accel, rho, tau0, sigma0, tab) < std::tie(o.maxiter, o.T, o.am, o.an, o.accel, o.rho, o.tau0, o.sigma0, o.tab);
+        return std::tie(maxiter, T, am, an, accel, variant, rho, tau0, sigma0, tab) <
+               std::tie(o.maxiter, o.T, o.am, o.an, o.accel, o.variant, o.rho, o.tau0, o.sigma0, o.tab);
     }
 };
 
@@ -1253,7 +1254,18 @@ int evaluate_common(bpltv_t* h, const double* alpha, int am, int an, double delt
 // ============================================================================================
 // Sum-of-regularisers model (sumregs_kernels.hpp; /root/reference/src/SumRegsLearningFunction.jl)
 // ============================================================================================
-constexpr int SR_R = 32;   // region of sr_tile_kernel<32, 32>: one pixel per thread
+// PDHG kernels of the three-dual model: params.variant 1 = sr_tile_kernel<32,32> (one pixel per thread), 2 =
+// sr_strip_kernel<3,48,16> (48 x 48 region, three pixels per thread); 0 = by image size.
+struct SrVariant {
+    int R, threads;
+    size_t lds;
+    void (*kernel)(SrArgs);
+};
+const SrVariant SR_VARIANTS[] = {
+    {32, 32 * 32, sr_lds_bytes(32, 32), &sr_tile_kernel<32, 32>},
+    {48, 48 * 16, sr_lds_bytes(48, 48), &sr_strip_kernel<3, 48, 16>},
+};
+constexpr int SR_NVARIANTS = 2;
 
 int sr_upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
     if (!alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
@@ -1286,8 +1298,8 @@ int sr_alloc(bpltv_t* h) {
     if (h->sr_ready) return BPLTV_OK;
     for (int s = 0; s < 2; ++s)
         for (int c = 0; c < 7; ++c) HIPCHK(h, hipMalloc((void**)&h->d_sr[s][c], h->tot * sizeof(double)));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&sr_tile_kernel<SR_R, SR_R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sr_lds_bytes(SR_R, SR_R)));
+    for (const SrVariant& v : SR_VARIANTS)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
     h->sr_ready = true;
     return BPLTV_OK;
 }
@@ -1307,7 +1319,25 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     rc = get_table(h, p, &d_tab, 18.0);   // ||G_f||^2 + ||G_b||^2 + ||G_c||^2 <= 8 + 8 + 2 (sumregs_oracle.c: SR_L)
     if (rc) return rc;
     const int M = h->M, N = h->N;
-    int T = p.tile_iters > 0 ? p.tile_iters : 4;   // halo 8, core 16 of the 32 x 32 region
+    if (p.reserved[0] < 0 || p.reserved[0] > SR_NVARIANTS) return set_err(h, BPLTV_E_ARG, "variant %d: the sum-of-regularisers model has 1..%d", p.reserved[0], SR_NVARIANTS);
+    int vi = p.reserved[0] - 1;
+    if (vi < 0) {
+        // Both kernels are VALU-issue bound.  One launch of T = 4 iterations costs about 16 us with two
+        // 32 x 32 workgroups per CU and about 20 us with the one 48 x 48 workgroup a CU holds; the 48 x 48 region
+        // recomputes 2.25 x instead of 4 x.  Rounds of workgroups over the CUs decide: the small batch (10 x 128^2:
+        // 490 tiles against 160 on 256 CUs) stays with the one-pixel kernel, anything of a few 256^2 images up goes
+        // to the strip kernel.
+        const int ncu = h->ncu > 0 ? h->ncu : 256;
+        auto tiles = [&](int R) {
+            const int Tt = std::max(1, std::min(4, std::min((M <= R) ? 4 : (R - 1) / 4, (N <= R) ? 4 : (R - 1) / 4)));
+            return (double)tile_count(M, R, 2 * Tt) * tile_count(N, R, 2 * Tt) * h->O;
+        };
+        const double c32 = 16.0 * std::ceil(tiles(32) / (2.0 * ncu)), c48 = 20.0 * std::ceil(tiles(48) / (1.0 * ncu));
+        vi = (M <= 32 && N <= 32) ? 0 : (c48 < c32 ? 1 : 0);
+    }
+    const SrVariant& V = SR_VARIANTS[vi];
+    const int SR_R = V.R;
+    int T = p.tile_iters > 0 ? p.tile_iters : 4;   // halo 8: core 16 of the 32 x 32, 32 of the 48 x 48 region
     auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 4; };   // 2 * halo = 4T must leave a core
     T = std::min(T, std::min(maxT(M, SR_R), maxT(N, SR_R)));
     if (T < 1) return set_err(h, BPLTV_E_ARG, "tile_iters must be >= 1");
@@ -1334,7 +1364,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
             a.it0 = it; a.nit = std::min(T, it1 - it);
             a.M = M; a.N = N; a.O = h->O; a.nTi = nTi; a.nTj = nTj; a.halo = 2 * T;
             a.first = (it == 0) ? 1 : 0;
-            hipLaunchKernelGGL((sr_tile_kernel<SR_R, SR_R>), dim3(grid), dim3(SR_R * SR_R), sr_lds_bytes(SR_R, SR_R), st, a);
+            hipLaunchKernelGGL(V.kernel, dim3(grid), dim3(V.threads), V.lds, st, a);
             cur = nxt;
         }
         return cur;
@@ -1375,7 +1405,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     bool done = false;
     if (p.use_graph && nl <= 50000) {
-        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, p.rho, p.tau0, p.sigma0, (const void*)d_tab};
+        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, vi, p.rho, p.tau0, p.sigma0, (const void*)d_tab};
         auto it = h->sr_graphs.find(key);
         if (it == h->sr_graphs.end()) {
             if (h->sr_graphs.size() >= 8) {

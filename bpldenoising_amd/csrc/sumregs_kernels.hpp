@@ -19,7 +19,7 @@
 
 namespace bpltv {
 
-constexpr size_t sr_lds_bytes(int RI, int RJ) { return sizeof(double) * 7 * (size_t)RI * RJ; }
+constexpr size_t sr_lds_bytes(int RI, int RJ) { return sizeof(double) * (7 * (size_t)RI * RJ + 1); }   // seven planes + one zero cell
 
 struct SrArgs {
     const double* in[7];   // x, yf1, yf2, yb1, yb2, yc1, yc2
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
     const bool hasL = gi > 0, hasR = gi < M - 1, hasU = gj > 0, hasD = gj < N - 1;
     const int nim = l - ((hasL && li > 0) ? 1 : 0), nip = l + ((hasR && li < RI - 1) ? 1 : 0);
     const int njm = l - ((hasU && lj > 0) ? RI : 0), njp = l + ((hasD && lj < RJ - 1) ? RI : 0);
+    // The four one-sided neighbour reads whose border value is the constant 0 address a zero cell behind the planes
+    // instead of being selected after the read (zf1m etc. are offsets into their own plane).
+    const int zf1m = hasL ? nim : (7 - 0) * RN, zf2m = hasU ? njm : (7 - 1) * RN;
+    const int zb1p = hasR ? nip : (7 - 2) * RN, zb2p = hasD ? njp : (7 - 3) * RN;
+    if (tid == 0) smem[7 * RN] = 0.0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) sy[c * RN + l] = y[c];
     __syncthreads();
@@ -100,12 +105,15 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
         const double* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < A.nit) ? it + 1 : it);
         const double ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
         // ---- primal step: div = (G_f^T y_f + G_b^T y_b) + G_c^T y_c in the oracle's gather order (sr_gradT_at)
-        const double f1m = sy[0 * RN + nim], f2m = sy[1 * RN + njm];
-        const double b1p = sy[2 * RN + nip], b2p = sy[3 * RN + njp];
+        const double f1m = sy[0 * RN + zf1m], f2m = sy[1 * RN + zf2m];   // 0 where the neighbour is outside the image
+        const double b1p = sy[2 * RN + zb1p], b2p = sy[3 * RN + zb2p];
         const double c1m = sy[4 * RN + nim], c1p = sy[4 * RN + nip];
         const double c2m = sy[5 * RN + njm], c2p = sy[5 * RN + njp];
-        const double tf = ((hasL ? f1m : 0.0) - (hasR ? y[0] : 0.0)) + ((hasU ? f2m : 0.0) - (hasD ? y[1] : 0.0));
-        const double tbk = ((hasL ? y[2] : 0.0) - (hasR ? b1p : 0.0)) + ((hasU ? y[3] : 0.0) - (hasD ? b2p : 0.0));
+        // The oracle's (hasR ? yf1 : 0) etc. need no select: a one-sided difference across the image border is x - x =
+        // +0, so yf1 on the last row, yf2 on the last column, yb1 on the first row and yb2 on the first column stay +0
+        // through every iteration (fma(sigma, +0, +0) = +0; the projection multiplies by a finite factor).
+        const double tf = (f1m - y[0]) + (f2m - y[1]);
+        const double tbk = (y[2] - b1p) + (y[3] - b2p);
         const double ca = hasL ? c1m : -y[4], cb = hasR ? c1p : -y[4];
         const double cc = hasU ? c2m : -y[5], cd = hasD ? c2p : -y[5];
         const double tc = 0.5 * (ca - cb) + 0.5 * (cc - cd);
@@ -140,14 +148,14 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
             n2v[k] = __builtin_fma(y2n, y2n, y1n * y1n);
             any_out |= n2v[k] > a * a;
         }
-        if (any_out) {   // a wave whose pixels all lie inside the three balls skips the rsqrt chains
+        (void)any_out;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double a = al[k];
+        for (int k = 0; k < 3; ++k) {   // per regulariser: lanes outside the ball project (a wave with none skips the chain)
+            const double a = al[k];
+            if (n2v[k] > a * a) {
                 const double v = a * rsqrt_nr(n2v[k]);
-                const bool outp = n2v[k] > a * a;
-                y[2 * k] = outp ? y[2 * k] * v : y[2 * k];
-                y[2 * k + 1] = outp ? y[2 * k + 1] * v : y[2 * k + 1];
+                y[2 * k] = y[2 * k] * v;
+                y[2 * k + 1] = y[2 * k + 1] * v;
             }
         }
 #pragma unroll
@@ -161,6 +169,181 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
         __hip_atomic_store(&A.out[0][idx], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int c = 0; c < 6; ++c) __hip_atomic_store(&A.out[1 + c][idx], y[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The same iteration with PJ pixels per thread, stacked along j (a thread owns the strip lj = PJ*tj .. PJ*tj + PJ-1 of
+// column li): region TI x (PJ*TJ).  48 x 48 with three pixels per thread has a 32 x 32 core at T = 4 -- redundancy 2.25
+// instead of the 4.0 of the one-pixel kernel -- and a 128^2 image is 4 x 4 tiles.  j-neighbours inside the strip stay
+// in registers: of the 12 LDS reads and 7 writes per pixel and iteration of sr_tile_kernel, 8 and 5.33 remain at
+// PJ = 3 (planes yf2 / yb2 are only read across a strip boundary, from the strip's last / first pixel; yc2 from both).
+// Same operation sequence per pixel: bit-identical to sr_tile_kernel and to the oracle.
+template <int PJ, int TI, int TJ>
+__global__ __launch_bounds__(TI* TJ) void sr_strip_kernel(SrArgs A) {
+    constexpr int RI = TI, RJ = PJ * TJ, RN = RI * RJ;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sy = smem;              // six planes [RJ][RI]
+    double* sxb = smem + 6 * RN;
+    const int tid = threadIdx.x;
+    const int li = tid % TI, tj = tid / TI, lj0 = PJ * tj;
+    const int tilesPerImg = A.nTi * A.nTj;
+    const int img = blockIdx.x / tilesPerImg;
+    const int t = blockIdx.x - img * tilesPerImg;
+    const int ta = t % A.nTi, tb = t / A.nTi;
+    int oi, ci0, ci1, oj, cj0, cj1;
+    tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
+    tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
+    const int M = A.M, N = A.N;
+    const size_t base = (size_t)img * M * N;
+    const int gi = oi + li, ci = min(gi, M - 1);
+    const size_t astride = (size_t)A.am * A.an;
+    double x[PJ], f[PJ], y[PJ][6], al[PJ][3], bc[PJ];
+    size_t g[PJ];
+    bool hasU[PJ], hasD[PJ];
+    // ---- prologue: all global loads first
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = oj + lj0 + pj, cj = min(gj, N - 1);
+        g[pj] = base + ci + (size_t)M * cj;
+        const size_t ai = sr_alpha_index(A.am, A.an, M, N, ci, cj);
+        f[pj] = A.f[g[pj]];
+        al[pj][0] = A.alpha[ai]; al[pj][1] = A.alpha[astride + ai]; al[pj][2] = A.alpha[2 * astride + ai];
+        if (!A.first) {
+            x[pj] = A.in[0][g[pj]];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) y[pj][c] = A.in[1 + c][g[pj]];
+        }
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = oj + lj0 + pj;
+        if (A.first) {
+            x[pj] = f[pj];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) y[pj][c] = 0.0;
+        }
+        if (!(gi < M && gj < N)) {
+            x[pj] = 0.0; f[pj] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) y[pj][c] = 0.0;
+            al[pj][0] = al[pj][1] = al[pj][2] = 0.0;
+        }
+        hasU[pj] = gj > 0;
+        hasD[pj] = gj < N - 1;
+    }
+    const bool hasL = gi > 0, hasR = gi < M - 1;
+    const int l0 = lj0 * RI + li, lE = l0 + (PJ - 1) * RI;   // the strip's first and last cell
+    const int dm = (hasL && li > 0) ? -1 : 0, dp = (hasR && li < RI - 1) ? 1 : 0;
+    // strip ends: the j-neighbour in the region, or a written cell of the same plane where it leaves the region or the
+    // image (there the value is either replaced by the border constant or belongs to a pixel outside the validity front)
+    const bool upIn = hasU[0] && lj0 > 0, dnIn = hasD[PJ - 1] && lj0 + PJ < RJ;
+    const int upC = upIn ? l0 - RI : l0, dnC = dnIn ? lE + RI : lE;   // planes written at both strip ends (yc2, xbar)
+    // yf2 is written at the strip's last cell only, yb2 at its first: outside the region a written cell of the own strip,
+    // outside the image the zero cell behind the planes (as zf1m / zb1p for the i-neighbours, see sr_tile_kernel)
+    const int upF = hasU[0] ? (upIn ? l0 - RI : lE) : (7 - 1) * RN;
+    const int dnB = hasD[PJ - 1] ? (dnIn ? lE + RI : l0) : (7 - 3) * RN;
+    const int zdm = hasL ? dm : (7 - 0) * RN - l0, zdp = hasR ? dp : (7 - 2) * RN - l0;   // relative to the strip's first cell
+    if (tid == 0) smem[7 * RN] = 0.0;
+    auto store_duals = [&]() {
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            const int l = l0 + pj * RI;
+            sy[0 * RN + l] = y[pj][0];
+            sy[2 * RN + l] = y[pj][2];
+            sy[4 * RN + l] = y[pj][4];
+            if (pj == PJ - 1) sy[1 * RN + l] = y[pj][1];
+            if (pj == 0) sy[3 * RN + l] = y[pj][3];
+            if (pj == 0 || pj == PJ - 1) sy[5 * RN + l] = y[pj][5];
+        }
+    };
+    store_duals();
+    __syncthreads();
+
+    const double rho = A.rho;
+    const double* __restrict__ row = A.tab + (size_t)TAB_STRIDE * A.it0;
+    double tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    for (int it = 0; it < A.nit; ++it) {
+        const double* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < A.nit) ? it + 1 : it);
+        const double ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        // ---- primal step (sr_tile_kernel's expression order)
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            const int l = l0 + pj * RI;
+            const double f1m = sy[0 * RN + (hasL ? l : l0) + zdm], b1p = sy[2 * RN + (hasR ? l : l0) + zdp];
+            const double c1m = sy[4 * RN + l + dm], c1p = sy[4 * RN + l + dp];
+            const double f2m = (pj > 0) ? y[pj > 0 ? pj - 1 : 0][1] : sy[1 * RN + upF];
+            const double c2m = (pj > 0) ? y[pj > 0 ? pj - 1 : 0][5] : sy[5 * RN + upC];
+            // inside the strip the j+1 neighbour is a register (an out-of-image pixel beyond the last column holds +-0:
+            // the select keeps the oracle's +0)
+            const bool hU = hasU[pj], hD = hasD[pj];
+            const double b2p = (pj < PJ - 1) ? (hD ? y[pj < PJ - 1 ? pj + 1 : pj][3] : 0.0) : sy[3 * RN + dnB];
+            const double c2p = (pj < PJ - 1) ? y[pj < PJ - 1 ? pj + 1 : pj][5] : sy[5 * RN + dnC];
+            const double tf = (f1m - y[pj][0]) + (f2m - y[pj][1]);   // selects dropped as in sr_tile_kernel
+            const double tbk = (y[pj][2] - b1p) + (y[pj][3] - b2p);
+            const double ca = hasL ? c1m : -y[pj][4], cb = hasR ? c1p : -y[pj][4];
+            const double cc = hU ? c2m : -y[pj][5], cd = hD ? c2p : -y[pj][5];
+            const double tc = 0.5 * (ca - cb) + 0.5 * (cc - cd);
+            const double div = (tf + tbk) + tc;
+            const double tt = div - f[pj];
+            const double xo = x[pj];
+            const double xn = __builtin_fma(-tau, tt, xo) * inv1ptau;
+            bc[pj] = __builtin_fma(-omega, xo, opw * xn);
+            x[pj] = xn;
+            sxb[l] = bc[pj];
+        }
+        __syncthreads();
+        // ---- dual steps
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            const int l = l0 + pj * RI;
+            const double bcc = bc[pj];
+            const double bp = sxb[l + dp], bm = sxb[l + dm];
+            const double cp = (pj < PJ - 1) ? (hasD[pj] ? bc[pj < PJ - 1 ? pj + 1 : pj] : bcc) : sxb[dnC];
+            const double cm = (pj > 0) ? bc[pj > 0 ? pj - 1 : 0] : sxb[upC];
+            double d1[3], d2[3];
+            d1[0] = bp - bcc; d2[0] = cp - bcc;
+            d1[1] = bcc - bm; d2[1] = bcc - cm;
+            d1[2] = 0.5 * (bp - bm); d2[2] = 0.5 * (cp - cm);
+            double n2v[3];
+            bool any_out = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double a = al[pj][k];
+                double y1n = __builtin_fma(sigma, d1[k], y[pj][2 * k]);
+                double y2n = __builtin_fma(sigma, d2[k], y[pj][2 * k + 1]);
+                if (rho != 0.0) {
+                    const double den = 1.0 + sigma * rho / a;
+                    y1n = y1n / den;
+                    y2n = y2n / den;
+                }
+                y[pj][2 * k] = y1n;
+                y[pj][2 * k + 1] = y2n;
+                n2v[k] = __builtin_fma(y2n, y2n, y1n * y1n);
+                any_out |= n2v[k] > a * a;
+            }
+            (void)any_out;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double a = al[pj][k];
+                if (n2v[k] > a * a) {
+                    const double v = a * rsqrt_nr(n2v[k]);
+                    y[pj][2 * k] = y[pj][2 * k] * v;
+                    y[pj][2 * k + 1] = y[pj][2 * k + 1] * v;
+                }
+            }
+        }
+        store_duals();
+        tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = oj + lj0 + pj;
+        if (gi >= ci0 && gi < ci1 && gj >= cj0 && gj < cj1) {
+            __hip_atomic_store(&A.out[0][g[pj]], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) __hip_atomic_store(&A.out[1 + c][g[pj]], y[pj][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -80,7 +80,8 @@ typedef struct bpltv_params {
                             bitwise the same for every number of GPUs (and equal to a single handle's);
                             0 (default) = one all-reduce(sum) of the per-device partial vectors           */
     int reserved[5];     /* tuning / measurement knobs, 0 = default:
-                            [0] PDHG kernel variant (1-based index into the variant table of bpltv.hip)
+                            [0] PDHG kernel variant (1-based index into the variant table of bpltv.hip; sum of
+                                regularisers: 1 = 32x32 region / 1 px per thread, 2 = 48x48 / 3 px per thread)
                             [1] number of independent launch chains (image groups replayed concurrently)
                             [2] 1 = replay those chains one after the other (isolated kernel timing)
                             [3] must be 0 (BPLTV_E_ARG otherwise); timing-experiment switches exist only in

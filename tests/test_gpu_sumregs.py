@@ -13,7 +13,7 @@ A3 = np.array([0.03, 0.02, 0.05])
 P3 = np.stack([np.array([[0.03, 0.05], [0.02, 0.04]]), np.array([[0.02, 0.03], [0.05, 0.02]]), np.array([[0.04, 0.02], [0.03, 0.06]])])
 
 
-@pytest.mark.parametrize("shape", [(2, 40, 33), (1, 128, 128), (3, 70, 96), (1, 20, 150)], ids=["40x33", "128", "70x96", "20x150"])
+@pytest.mark.parametrize("shape", [(2, 40, 33), (1, 128, 128), (3, 70, 96), (1, 20, 150), (2, 30, 31)], ids=["40x33", "128", "70x96", "20x150", "30x31"])
 @pytest.mark.parametrize("alpha", [A3, P3, "map"], ids=["vector", "patch22", "map"])
 def test_pdhg_bit_exact(gpu_solver_cls, oracle, shape, alpha):
     O, N, M = shape
@@ -22,10 +22,27 @@ def test_pdhg_bit_exact(gpu_solver_cls, oracle, shape, alpha):
         alpha = 0.02 + 0.05 * np.random.default_rng(1).random((3, N, M))
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
-    for it, T_ in ((37, 0), (200, 3), (64, 1)):
-        u = s.sumregs_denoise(alpha, maxiter=it, tile_iters=T_)
-        assert np.array_equal(u, oracle.sumregs_pdhg(f, alpha, maxiter=it, nthreads=4)), (it, T_)
+    for it, T_, var in ((37, 0, 0), (200, 3, 1), (64, 1, 2), (200, 4, 2), (37, 2, 1)):   # both kernels, several fusion depths
+        u = s.sumregs_denoise(alpha, maxiter=it, tile_iters=T_, variant=var)
+        assert np.array_equal(u, oracle.sumregs_pdhg(f, alpha, maxiter=it, nthreads=4)), (it, T_, var)
+        assert s.stats()["region_i"] == ({1: 32, 2: 48}[var] if var else 32)   # these batches are small: the one-pixel kernel
     assert np.abs(s.sumregs_denoise(np.zeros(3), maxiter=9) - f).max() < 1e-15       # alpha = 0: u = f
+    s.close()
+
+
+def test_larger_batches_use_the_strip_kernel(gpu_solver_cls, oracle):
+    """4 x 256 x 256: the library picks sr_strip_kernel<3,48,16> (48 x 48 region, three pixels per thread, j-neighbours in
+    registers); bit-exact against the oracle and against the one-pixel kernel."""
+    ub, f = synth_batch(4, 256, 256, seed=77)
+    alpha = 0.02 + 0.05 * np.random.default_rng(3).random((3, 256, 256))
+    s = gpu_solver_cls(256, 256, 4)
+    s.set_data(ub, f)
+    for a in (A3, alpha):
+        u = s.sumregs_denoise(a, maxiter=61)
+        st = s.stats()
+        assert (st["region_i"], st["region_j"], st["tile_iters"]) == (48, 48, 4)
+        assert np.array_equal(u, oracle.sumregs_pdhg(f, a, maxiter=61, nthreads=8))
+        assert np.array_equal(u, s.sumregs_denoise(a, maxiter=61, variant=1))
     s.close()
 
 

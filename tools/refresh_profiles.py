@@ -127,7 +127,7 @@ def publish(tag):
             lines = [l for l in open(p) if l.startswith("{")]
             if lines:
                 open(os.path.join(PRO, "%s_%s.json" % (tag, name)), "w").write(lines[-1]); copied.append(name)
-    for log in ("eval_cfg5.log", "sumregs_time.log", "eval_128.log", "nd_unit_time.log", "pmc_hb_sq.log"):
+    for log in ("eval_cfg5.log", "sumregs_time.log", "sumregs_large.log", "eval_128.log", "nd_unit_time.log", "pmc_hb_sq.log"):
         p = os.path.join(SRC, log)
         if os.path.exists(p):
             with open(os.path.join(PRO, "%s_%s" % (tag, log)), "w") as fh:
