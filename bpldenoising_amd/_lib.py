@@ -51,7 +51,7 @@ class BpltvStats(C.Structure):
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
-        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm", 4: "band-lu", 5: "nd"}.get(self.adjoint_method, "")
+        d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm", 4: "band-lu", 5: "nd", 6: "nd-lu"}.get(self.adjoint_method, "")
         d["hb_sync"] = {0: "", 1: "event", 2: "value"}.get(self.hb_sync, "")
         d["collective"] = {0: "none", 1: "ncclAllReduce", 2: "ncclAllGather+ordered sum", 3: "host sum"}.get(self.collective, "")
         return d

@@ -207,7 +207,8 @@ struct bpltv_handle {
     bool last_is_sr = false;                        // the last solve was the sum-of-regularisers model
     double *d_srcoef = nullptr, *d_srdiag = nullptr, *d_srw = nullptr, *d_srgpix = nullptr;
     HbBandSolver hb_sr;
-    HbLuSolver lu_sr;             // non-symmetric row-scaled system of sumregs_gradient_reg with a patch parameter
+    HbLuSolver lu_sr;             // non-symmetric row-scaled system of sumregs_gradient_reg with a patch parameter: banded LU (cross-check)
+    NdSolver nd_sr_lu;            // ... the same system by nested dissection (LU variant; the default)
     bool lu_sr_ready = false;
     double* d_srdiagU = nullptr;  // its upper diagonals (7 planes)
     std::map<SrGraphKey, hipGraphExec_t> sr_graphs;
@@ -859,9 +860,9 @@ int bcr_alloc(bpltv_t* h, int* Oc) {
 }
 
 // Nested-dissection Cholesky (nd_solver.hpp): tree built once per handle, workspace for groups of *Oc images.
-int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, int* Oc) {
+int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, int* Oc, bool lu = false) {
     if (!nd.built) {
-        const int rc = nd.build(h->M, h->N, st);
+        const int rc = nd.build(h->M, h->N, st, 0, lu);
         if (rc) { const std::string m = nd.err; nd.release(); return set_err(h, rc, "adjoint gradient (%s): %s", what, m.c_str()); }
     }
     const size_t per = nd.bytes_per_image();
@@ -930,7 +931,7 @@ int band_alloc(bpltv_t* h) {
 }
 
 // ---- the three factorisations of the reduced adjoint system ----------------------
-enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3, ADJ_BAND_LU = 4, ADJ_ND = 5 };   // also bpltv_stats_t::adjoint_method
+enum AdjMethod { ADJ_BAND_LDS = 1, ADJ_BCR = 2, ADJ_BAND_HBM = 3, ADJ_BAND_LU = 4, ADJ_ND = 5, ADJ_ND_LU = 6 };   // also bpltv_stats_t::adjoint_method
 
 // Pick the factorisation for this handle (params.reserved[4]: 0 automatic, 1 banded Cholesky, 2 block cyclic
 // reduction, 3 nested dissection), make sure its workspace exists and say in groups of how many images the gradient
@@ -1480,7 +1481,8 @@ int sr_band_alloc(bpltv_t* h) {
 // Gradient of the sum-of-regularisers model.  Factorisations of its 13-point system: nested dissection (default,
 // separators two pixels wide, image groups when the workspace does not fit), the HBM band at bandwidth 2M
 // (params.reserved[4] = 1), and -- sumregs_gradient_reg with a patch parameter, whose row-scaled system is not
-// symmetric (SumRegsLearningFunction.jl:250) -- the banded LU.
+// symmetric (SumRegsLearningFunction.jl:250) -- the LU variant of the nested dissection (banded LU with
+// params.reserved[4] = 1).
 int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int reg, const bpltv_params& p, double* d_out,
                          double kappa_scale) {
     int rc = sr_adj_alloc(h);
@@ -1492,22 +1494,27 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     const bool rowsc = reg && patch;
     const bool lu = rowsc || (force_lu && force_lu[0] == '1');
     if (p.reserved[4] == 2) return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction applies to the TV model only");
-    const bool band = !lu && p.reserved[4] == 1;
+    const bool band = p.reserved[4] == 1;     // the band solvers (Cholesky / LU) instead of nested dissection
     int Oc = O;
-    if (lu) {
-        if (rowsc && !(h->alpha_min > 0.0))
-            return set_err(h, BPLTV_E_ARG, "sumregs_gradient_reg with a patch parameter needs every entry > 0 (min = %g)", h->alpha_min);
+    if (lu && rowsc && !(h->alpha_min > 0.0))
+        return set_err(h, BPLTV_E_ARG, "sumregs_gradient_reg with a patch parameter needs every entry > 0 (min = %g)", h->alpha_min);
+    if (lu && !h->d_srdiagU) {
+        rc = alloc_all(h, {{(void**)&h->d_srdiagU, 7 * tot * sizeof(double)}}, "sum-of-regularisers adjoint (upper diagonals)");
+        if (rc) return rc;
+    }
+    if (lu && !band) {
+        rc = nd_alloc(h, h->nd_sr_lu, nd_stencil_sr(), "sum of regularisers, nested dissection (LU)", &Oc, true);
+        if (rc) return rc;
+    } else if (lu) {
         if (!h->lu_sr_ready) {
             const int n = (int)h->npx, bw = std::min(2 * M, n - 1);
             size_t freeb = 0, totalb = 0;
             (void)hipMemGetInfo(&freeb, &totalb);
-            const size_t need = h->lu_sr.bytes_needed(bw, n, O) + 7 * tot * sizeof(double);
+            const size_t need = h->lu_sr.bytes_needed(bw, n, O);
             if (need + (2ull << 30) > freeb)
                 return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint (banded LU): %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
-            rc = alloc_all(h, {{(void**)&h->d_srdiagU, 7 * tot * sizeof(double)}}, "sum-of-regularisers adjoint (banded LU)");
-            if (rc) return rc;
             const int rc2 = h->lu_sr.alloc(bw, n, O, h->stream);
-            if (rc2) { (void)hipFree(h->d_srdiagU); h->d_srdiagU = nullptr; return set_err(h, rc2, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str()); }
+            if (rc2) return set_err(h, rc2, "sum-of-regularisers adjoint (banded LU): %s", h->lu_sr.err.c_str());
             h->lu_sr_ready = true;
         }
     } else if (band) {
@@ -1544,7 +1551,10 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
         BandDiags D;
         D.planes = diag; D.tot = tot; D.nd = 7;
         D.off[0] = 0; D.off[1] = 1; D.off[2] = 2; D.off[3] = M - 1; D.off[4] = M; D.off[5] = M + 1; D.off[6] = 2 * M;
-        if (lu) {
+        if (lu && !band) {
+            rc = h->nd_sr_lu.factor_lu(diag, diagU, tot, nimg, dfail);
+            if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (nested dissection, LU): %s", h->nd_sr_lu.err.c_str());
+        } else if (lu) {
             BandDiags DU = D;
             DU.planes = diagU;
             rc = h->lu_sr.factor(D, DU, dfail);
@@ -1561,7 +1571,8 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
             hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, w, M, N, nimg, out, rowscale, am, an);
         };
         auto solve = [&](double* v, double* acc) {
-            if (lu) h->lu_sr.solve(v, acc, h->d_gpix);
+            if (lu && !band) (void)h->nd_sr_lu.solve(v, acc, nimg);
+            else if (lu) h->lu_sr.solve(v, acc, h->d_gpix);
             else if (band) h->hb_sr.solve(v, acc, h->d_gpix);
             else (void)h->nd_sr.solve(v, acc, nimg);
         };
@@ -1601,14 +1612,15 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
     h->st.adjoint_ms = ms;
     h->st.reg_gradient_used = reg;
-    h->st.adjoint_method = lu ? (int)ADJ_BAND_LU : (band ? (int)ADJ_BAND_HBM : (int)ADJ_ND);
+    h->st.adjoint_method = lu ? (band ? (int)ADJ_BAND_LU : (int)ADJ_ND_LU) : (band ? (int)ADJ_BAND_HBM : (int)ADJ_ND);
     h->st.adjoint_chunks = chunks;
-    h->st.hb_sync = band ? (h->hb_sr.value_sync ? 2 : 1) : 0;
+    h->st.hb_sync = (band && !lu) ? (h->hb_sr.value_sync ? 2 : 1) : 0;
     h->st.kappa_used = reg ? 0.0 : kact;
     double worst = 0.0, worst_raw = 0.0;
     for (int k = 0; k < O; ++k) {
         if (fail[k] != 0)
-            return set_err(h, BPLTV_E_NUMERIC, lu ? "sum-of-regularisers adjoint, banded LU without pivoting: zero, tiny or non-finite pivot at column %d of image %d"
+            return set_err(h, BPLTV_E_NUMERIC, lu ? (band ? "sum-of-regularisers adjoint, banded LU without pivoting: zero, tiny or non-finite pivot at column %d of image %d"
+                                                          : "sum-of-regularisers adjoint, LU without pivoting: zero, tiny or non-finite pivot at front %d of image %d")
                                                   : (band ? "sum-of-regularisers adjoint Cholesky: non-positive pivot at column %d of image %d"
                                                           : "sum-of-regularisers adjoint Cholesky: non-positive pivot at front %d of image %d"), fail[k] - 1, k);
         const double* q = &resn[4 * (size_t)k];
@@ -2104,6 +2116,7 @@ int bpltv_destroy(bpltv_t* h) {
     h->hb.release();
     h->nd.release();
     h->nd_sr.release();
+    h->nd_sr_lu.release();
     h->hb_sr.release();
     h->lu_sr.release();
     if (h->d_srdiagU) (void)hipFree(h->d_srdiagU);

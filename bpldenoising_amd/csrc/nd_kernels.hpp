@@ -45,12 +45,17 @@ struct NdArgs {
     const int4* orig;          // (r, c, plane, pixel)
     const int* inv;            // parent -> child maps of the large-regime fronts (NdNodeDev::inv_off)
     const double* planes;      // assembled diagonals: planes[plane * tot + img * n + pixel]
+    const double* planes2;     // the diagonals of the other triangle (LU variant; = planes for a symmetric matrix)
     size_t tot;
     int n;                     // pixels per image
     double* fac;               // [nimg][fac_stride]
+    double* fac2;              // LU variant: the factor columns of the other triangle (second operand of the rank updates;
+                               // = fac for Cholesky)
     long long fac_stride;
     double* ws_mine;           // update matrices of this level   [nimg][ws_mine_stride]
     const double* ws_child;    // update matrices of the children [nimg][ws_child_stride]
+    double* ws_mine2;          // LU variant, small fronts: the transposed upper triangles (nd_front_small_lu_kernel)
+    const double* ws_child2;
     long long ws_mine_stride, ws_child_stride;
     int node0;                 // first node of the batch: blockIdx.y = node - node0
     int* fail;                 // [nimg]: node + 1 of the first non-positive pivot
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
         for (int e = tid; e < v.orig_cnt; e += NT) {
             const int4 o = A.orig[v.orig_off + e];
             const int r = o.x < p ? o.x : o.x + sh, c = o.y;   // c is a pivot
-            S[r + ld * c] += pl[(size_t)o.z * A.tot + o.w];
+            S[r + ld * c] += pl[(size_t)(o.z & 15) * A.tot + o.w];
         }
     }
     __syncthreads();
@@ -294,9 +299,10 @@ __global__ __launch_bounds__(256) void nd_orig_kernel(NdArgs A) {
     const int f = v.p + v.b;
     double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
     const double* pl = A.planes + (size_t)img * A.n;
+    const double* pl2 = A.planes2 + (size_t)img * A.n;   // entries whose row is the smaller pixel (ND_ORIG_UPPER)
     for (int e = threadIdx.x; e < v.orig_cnt; e += 256) {
         const int4 o = A.orig[v.orig_off + e];
-        fc[o.x + (size_t)f * o.y] += pl[(size_t)o.z * A.tot + o.w];
+        fc[o.x + (size_t)f * o.y] += ((o.z & 16) ? pl2 : pl)[(size_t)(o.z & 15) * A.tot + o.w];
     }
 }
 
@@ -328,7 +334,8 @@ __global__ __launch_bounds__(BCR_PT) void nd_potrf_kernel(NdArgs A, int k) {
 // Rows below the diagonal block of panel k: L(r, c) = sum_kk A(r, kk) W(c, kk), in place.  One workgroup owns 64 rows
 // and computes both 64-column halves before it writes (its rows are read by nobody else).
 // grid (row tiles, nodes, nimg), block BG_T.
-__global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
+// dense != 0 (LU variant): W is the full transposed inverse of the diagonal block, not a triangle.
+__global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k, int dense) {
     __shared__ double lds[BG_LDS];
     const int node = A.node0 + blockIdx.y, img = blockIdx.z, tid = threadIdx.x;
     const NdNodeDev v = A.nodes[node];
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
         for (int i = 0; i < 4; ++i) acc[h].c[i >> 1][i & 1] = bcr_d4{0.0, 0.0, 0.0, 0.0};
         if (h >= nhalf) continue;
         const int cc0 = 64 * h;
-        const int kend = min(nb, cc0 + 64);                 // W(c, kk) = 0 for kk > c
+        const int kend = dense ? nb : min(nb, cc0 + 64);    // Cholesky: W(c, kk) = 0 for kk > c
         const int nchunk = (kend + BG_KC - 1) / BG_KC;
         double va[8], vb[8];
         hb2_fetch_dense(Ar, f, rmax, kend, 0, 0, tid, va);
@@ -386,8 +393,10 @@ __global__ __launch_bounds__(BG_T) void nd_trsm_kernel(NdArgs A, int k) {
 //   X: rows relative to Xb (leading dimension ldx), nrow rows, depth kdepth
 //   Out(R, C) at Ob[R + ldo C], R in [0, nrow), C in [0, ncol), R + roff >= C is written (roff: row offset of the
 //   output region against its column numbering, 0 for square regions)
-__device__ __forceinline__ void nd_tile_rank_update(const double* __restrict__ Xb, int ldx, int nrow, int kdepth, int ta, int tb,
-                                                    double* __restrict__ Ob, size_t ldo, int ncol, double* __restrict__ lds) {
+// Yb: the second operand, A(R, C) -= sum_kk X(R, kk) Y(C, kk) (LU variant: the other triangle's factor columns); = Xb for
+// Cholesky.
+__device__ __forceinline__ void nd_tile_rank_update(const double* __restrict__ Xb, const double* __restrict__ Yb, int ldx, int nrow, int kdepth,
+                                                    int ta, int tb, double* __restrict__ Ob, size_t ldo, int ncol, double* __restrict__ lds) {
     const int tid = threadIdx.x;
     double* As = lds;
     double* Bs = lds + BG_KC * BG_LD;
@@ -397,7 +406,7 @@ __device__ __forceinline__ void nd_tile_rank_update(const double* __restrict__ X
     const int nchunk = (kdepth + BG_KC - 1) / BG_KC;
     double va[8], vb[8];
     hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * ta, 0, tid, va);
-    hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * tb, 0, tid, vb);
+    hb2_fetch_dense(Yb, ldx, nrow, kdepth, 64 * tb, 0, tid, vb);
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();
         bg_stage<true>(As, tid, va);
@@ -405,7 +414,7 @@ __device__ __forceinline__ void nd_tile_rank_update(const double* __restrict__ X
         __syncthreads();
         if (ch + 1 < nchunk) {
             hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * ta, (ch + 1) * BG_KC, tid, va);
-            hb2_fetch_dense(Xb, ldx, nrow, kdepth, 64 * tb, (ch + 1) * BG_KC, tid, vb);
+            hb2_fetch_dense(Yb, ldx, nrow, kdepth, 64 * tb, (ch + 1) * BG_KC, tid, vb);
         }
         hb2_mma_chunk(As, Bs, acc);
     }
@@ -445,7 +454,8 @@ __global__ __launch_bounds__(BG_T) void nd_syrk_kernel(NdArgs A, int k) {
     const int nrow = f - s0, ncol = p - s0;
     if (64 * ta >= nrow || 64 * tb >= ncol) return;
     double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
-    nd_tile_rank_update(fc + s0 + (size_t)f * c0, f, nrow, HB2_NB, ta, tb, fc + s0 + (size_t)f * s0, (size_t)f, ncol, lds);
+    const double* f2 = A.fac2 + (size_t)img * A.fac_stride + v.fac_off;
+    nd_tile_rank_update(fc + s0 + (size_t)f * c0, f2 + s0 + (size_t)f * c0, f, nrow, HB2_NB, ta, tb, fc + s0 + (size_t)f * s0, (size_t)f, ncol, lds);
 }
 
 // U -= L21 L21^T (depth p).  grid (lower tiles of ceil(b / 64), nodes, nimg).
@@ -458,8 +468,235 @@ __global__ __launch_bounds__(BG_T) void nd_schur_kernel(NdArgs A) {
     nd_tri_decode((int)blockIdx.x, ta, tb);
     if (64 * ta >= b) return;
     const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* f2 = A.fac2 + (size_t)img * A.fac_stride + v.fac_off;
     double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
-    nd_tile_rank_update(fc + p, f, b, p, ta, tb, U, (size_t)b, b, lds);
+    nd_tile_rank_update(fc + p, f2 + p, f, b, p, ta, tb, U, (size_t)b, b, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LU variant (structurally symmetric, numerically non-symmetric matrices: the row-scaled system of
+// sumregs_gradient_reg with a patch parameter, /root/reference/src/SumRegsLearningFunction.jl:250).  Same tree, same
+// maps.  A front keeps its two triangles apart -- FL: lower triangle and diagonal, FU: the strict upper triangle
+// TRANSPOSED (FU(R, C) = F(C, R), R > C) -- each in the layout of the Cholesky front (factor columns f x p, update matrix
+// b x b), so the gather, matrix-entry, trsm and rank-update kernels above run on either with the pointers exchanged.
+// Block LU without pivoting with INVERTED diagonal blocks, per 128-column pivot panel k (D = F_kk):
+//     L'(R, k) = F(R, k) D^-1   (rows below, nd_trsm_kernel with the dense W = D^-T),   U(k, C) = F(k, C) stays,
+//     F(R, C) -= L'(R, k) U(k, C):  FL(R, C) -= L'(R, :) FU(C, :)^T  (R >= C),   FU(C, R) -= FU(C, :) L'(R, :)^T  (C > R).
+// Substitutions: forward y_k = w_k, rows below lose L' y_k; backward x_k = D^-1 (y_k - U(k, after) x_after); D^-T is
+// kept in the diagonal slot of both triangles.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int NDG_T = 1024;
+inline size_t nd_getri_lds() { return sizeof(double) * HB2_NB * (HB2_NB + 1); }
+// A pivot that is zero, not finite, or has lost every digit against the diagonal entry it started from means the
+// elimination without pivoting has broken down (hb_getri_kernel's criterion).
+__device__ __forceinline__ bool nd_lu_pivot_bad(double piv, double d0) { return !(fabs(piv) > 2.220446049250313e-16 * d0 && fabs(piv) < 1.7e308); }
+
+// Inverse of the diagonal block of pivot panel k by Gauss-Jordan elimination without pivoting, in LDS; its transpose
+// replaces the block in both triangles.  A.fac = FL, A.fac2 = FU.  grid (nodes, nimg), block NDG_T, LDS nd_getri_lds().
+__global__ __launch_bounds__(NDG_T) void nd_getri_kernel(NdArgs A, int k) {
+    extern __shared__ double S[];
+    __shared__ double d0[HB2_NB];
+    constexpr int MP = HB2_NB, ld = MP + 1;
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, f = p + v.b, c0 = HB2_NB * k;
+    if (c0 >= p) return;
+    const int nb = min(HB2_NB, p - c0);
+    double* bL = A.fac + (size_t)img * A.fac_stride + v.fac_off + c0 + (size_t)f * c0;
+    double* bU = A.fac2 + (size_t)img * A.fac_stride + v.fac_off + c0 + (size_t)f * c0;
+    for (int e = tid; e < MP * MP; e += NDG_T) {
+        const int r = e % MP, c = e / MP;
+        double x = (r == c) ? 1.0 : 0.0;   // identity padding
+        if (r < nb && c < nb) x = (r >= c) ? bL[r + (size_t)f * c] : bU[c + (size_t)f * r];
+        S[r + ld * c] = x;
+        if (r == c) d0[r] = fabs(x);
+    }
+    __syncthreads();
+    const int j = tid & (MP - 1), i0 = tid >> 7;   // thread: column j, rows i0 + 8 m
+    int badk = -1;
+    for (int kk = 0; kk < nb; ++kk) {
+        const double piv = S[kk + ld * kk];
+        if (badk < 0 && nd_lu_pivot_bad(piv, d0[kk])) badk = kk;
+        const double pinv = 1.0 / piv;
+        const double rk = (j == kk) ? pinv : S[kk + ld * j] * pinv;
+        double nv[16];
+#pragma unroll
+        for (int mq = 0; mq < 16; ++mq) {
+            const int i = i0 + 8 * mq;
+            const double fi = S[i + ld * kk];
+            const double old = (j == kk) ? 0.0 : S[i + ld * j];
+            nv[mq] = (i == kk) ? rk : old - fi * rk;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mq = 0; mq < 16; ++mq) S[i0 + 8 * mq + ld * j] = nv[mq];
+        __syncthreads();
+    }
+    if (badk >= 0 && tid == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    for (int e = tid; e < nb * nb; e += NDG_T) {
+        const int r = e % nb, c = e / nb;
+        const double x = S[c + ld * r];   // slot(r, c) = D^-1(c, r)
+        bL[r + (size_t)f * c] = x;
+        bU[r + (size_t)f * c] = x;
+    }
+}
+
+// Small fronts of the LU variant: the whole front (both triangles) in LDS, one workgroup per (front, image).
+// A.planes / planes2 = lower / upper diagonals, A.fac / fac2 = FL / FU, A.ws_mine / ws_mine2 and ws_child / ws_child2 =
+// the update matrices' lower (with diagonal) / transposed strict upper triangles.  Gauss-Jordan inverse of the pivot
+// block (p <= 48), L' = F21 D^-1 and F22 -= L' F12 on the f64 MFMA.  grid (nodes, nimg), block NDS_T, LDS nd_small_lds(MPmax).
+__global__ __launch_bounds__(NDS_T) void nd_front_small_lu_kernel(NdArgs A) {
+    extern __shared__ double S[];
+    __shared__ int cmL[2][128];
+    constexpr int NT = NDS_T, NW = NT / 64;
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, p16 = nd_up16(p), sh = p16 - p;
+    const int MP = nd_up16(p16 + b), ld = MP + 1, Pp = p16 >> 4, P = MP >> 4;
+    double* d0 = S + (size_t)ld * MP;   // [MP]
+    NdNodeDev ch[2];
+    int bc[2] = {0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn >= 0) { ch[ci] = A.nodes[cn]; bc[ci] = ch[ci].b; }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+        for (int kk = tid; kk < bc[ci]; kk += NT) {
+            const int R = A.cmap[ch[ci].cmap_off + kk];
+            cmL[ci][kk] = R < p ? R : R + sh;
+        }
+    for (int e = tid; e < ld * MP + MP; e += NT) S[e] = 0.0;
+    __syncthreads();
+    for (int kk = p + tid; kk < p16; kk += NT) S[kk + ld * kk] = 1.0;   // identity padding of the pivot block
+    {
+        const double* plL = A.planes + (size_t)img * A.n;
+        const double* plU = A.planes2 + (size_t)img * A.n;
+        for (int e = tid; e < v.orig_cnt; e += NT) {
+            const int4 o = A.orig[v.orig_off + e];
+            const int r = o.x < p ? o.x : o.x + sh, c = o.y;   // c is a pivot
+            const size_t at = (size_t)(o.z & 15) * A.tot + o.w;
+            const bool up = (o.z & 16) != 0;                   // F(r, c) is an entry of A's upper triangle
+            S[r + ld * c] += (up ? plU : plL)[at];
+            if (r != c) S[c + ld * r] += (up ? plL : plU)[at];
+        }
+    }
+    __syncthreads();
+    for (int ci = 0; ci < 2; ++ci) {
+        if (bc[ci] == 0) continue;
+        const double* UL = A.ws_child + (size_t)img * A.ws_child_stride + ch[ci].u_off;
+        const double* UU = A.ws_child2 + (size_t)img * A.ws_child_stride + ch[ci].u_off;
+        const int n = bc[ci];
+        const int* cm = cmL[ci];
+        for (int j = wave; j < n; j += NW)
+            for (int i = j + lane; i < n; i += 64) {
+                const double xl = UL[i + (size_t)n * j];
+                const double xu = (i > j) ? UU[i + (size_t)n * j] : 0.0;
+                S[cm[i] + ld * cm[j]] += xl;
+                if (i > j) S[cm[j] + ld * cm[i]] += xu;
+            }
+        __syncthreads();
+    }
+    // ---- D^-1 in place (first p steps; the padding is an identity block)
+    for (int kk = tid; kk < p16; kk += NT) d0[kk] = fabs(S[kk + ld * kk]);
+    __syncthreads();
+    {
+        const int ne = p16 * p16;
+        int badk = -1;
+        for (int kk = 0; kk < p; ++kk) {
+            const double piv = S[kk + ld * kk];
+            if (badk < 0 && nd_lu_pivot_bad(piv, d0[kk])) badk = kk;
+            const double pinv = 1.0 / piv;
+            double nv[9];   // 48 * 48 / 256
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                const int e = tid + NT * m;
+                if (e < ne) {
+                    const int i = e % p16, j = e / p16;
+                    const double rk = (j == kk) ? pinv : S[kk + ld * j] * pinv;
+                    const double fi = S[i + ld * kk];
+                    const double old = (j == kk) ? 0.0 : S[i + ld * j];
+                    nv[m] = (i == kk) ? rk : old - fi * rk;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                const int e = tid + NT * m;
+                if (e < ne) S[(e % p16) + ld * (e / p16)] = nv[m];
+            }
+            __syncthreads();
+        }
+        if (badk >= 0 && tid == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    }
+    // ---- L' = F21 D^-1: a wave per boundary tile row, all Pp (<= 3) column tiles before it writes
+    for (int i = Pp + wave; i < P; i += NW) {
+        bcr_d4 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = bcr_d4{0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < Pp; ++q) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double a = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < Pp) acc[c] = bcr_mfma(a, S[(16 * q + 4 * kk + lk) + ld * (16 * c + lr)], acc[c]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < Pp) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * c + lr)] = acc[c][g];
+            }
+    }
+    __syncthreads();
+    // ---- F22 -= L' F12, every tile of the boundary square
+    {
+        const int m = P - Pp;
+        for (int t = wave; t < m * m; t += NW) {
+            const int i = Pp + t % m, j = Pp + t / m;
+            bcr_d4 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)];
+            for (int q = 0; q < Pp; ++q) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = S[(16 * i + lr) + ld * (16 * q + 4 * kk + lk)];
+                    const double bb = S[(16 * q + 4 * kk + lk) + ld * (16 * j + lr)];
+                    acc = bcr_mfma(-a, bb, acc);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) S[(16 * i + lk + 4 * g) + ld * (16 * j + lr)] = acc[g];
+        }
+    }
+    __syncthreads();
+    // ---- results: FL rows [p, f) = L'; FU rows [0, p) = D^-T, rows [p, f) = F12^T; update matrix in two triangles
+    double* fL = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    double* fU = A.fac2 + (size_t)img * A.fac_stride + v.fac_off;
+    for (int c = wave; c < p; c += NW)
+        for (int r = lane; r < f; r += 64) {
+            if (r < p) {
+                const double x = S[c + ld * r];
+                fL[r + (size_t)f * c] = x;
+                fU[r + (size_t)f * c] = x;
+            } else {
+                fL[r + (size_t)f * c] = S[(r + sh) + ld * c];
+                fU[r + (size_t)f * c] = S[c + ld * (r + sh)];
+            }
+        }
+    double* UL = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    double* UU = A.ws_mine2 + (size_t)img * A.ws_mine_stride + v.u_off;
+    for (int j = wave; j < b; j += NW)
+        for (int i = j + lane; i < b; i += 64) {
+            UL[i + (size_t)b * j] = S[(p16 + i) + ld * (p16 + j)];
+            UU[i + (size_t)b * j] = (i > j) ? S[(p16 + j) + ld * (p16 + i)] : 0.0;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -470,6 +707,10 @@ struct NdSolveArgs {
     const int* pix;
     const int* cmap;
     const double* fac;
+    const double* fac2;     // LU variant: the factor columns of the upper triangle (backward substitution)
+    int lu;                 // 0: Cholesky.  1: block LU with inverted diagonal blocks -- forward: y_k = w_k (no triangular
+                            // factor to apply), rows below lose L' y_k; backward: x_k = D_k^-1 (y_k - U_k,after x_after),
+                            // D_k^-1 stored transposed in the diagonal slot of fac2
     long long fac_stride;
     double* vec;            // [nimg][n]: right-hand side in, solution out
     double* y;              // [nimg][n]: forward result
@@ -507,9 +748,11 @@ __global__ __launch_bounds__(64) void nd_fwd_small_kernel(NdSolveArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
     double* yo = A.y + (size_t)img * A.n;
-    for (int r = lane; r < p; r += 64) {          // y = W w_p (W lower triangular, zeros stored above)
+    for (int r = lane; r < p; r += 64) {          // y = W w_p (W lower triangular, zeros stored above); LU: y = w_p
         double acc = 0.0;
-        for (int c = 0; c <= r; ++c) acc = __builtin_fma(fc[r + (size_t)f * c], w[c], acc);
+        if (A.lu) acc = w[r];
+        else
+            for (int c = 0; c <= r; ++c) acc = __builtin_fma(fc[r + (size_t)f * c], w[c], acc);
         yv[r] = acc;
         yo[px[r]] = acc;
     }
@@ -536,7 +779,7 @@ __global__ __launch_bounds__(64) void nd_bwd_small_kernel(NdSolveArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* fc = (A.lu ? A.fac2 : A.fac) + (size_t)img * A.fac_stride + v.fac_off;
     for (int c = lane; c < p; c += 64) {
         double acc = yo[px[c]];
         const double* col = fc + p + (size_t)f * c;
@@ -550,7 +793,7 @@ __global__ __launch_bounds__(64) void nd_bwd_small_kernel(NdSolveArgs A) {
     for (int c = lane; c < p; c += 64) {
         double acc = 0.0;
         const double* col = fc + (size_t)f * c;
-        for (int r = c; r < p; ++r) acc = __builtin_fma(col[r], z[r], acc);
+        for (int r = A.lu ? 0 : c; r < p; ++r) acc = __builtin_fma(col[r], z[r], acc);
         x[px[c]] = acc;
         if (ac) ac[px[c]] += acc;
     }
@@ -594,23 +837,25 @@ __global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A, int 
     for (int c0 = 0; c0 < p; c0 += HB2_NB) {
         const int nb = min(HB2_NB, p - c0);
         // y_k = W_kk wf_k: thread (row r128, column group g8)
-        {
+        if (A.lu) {   // block LU: y_k = wf_k
+            if (tid < nb) yo[px[c0 + tid]] = wf[c0 + tid];
+        } else {
             double acc = 0.0;
             if (r128 < nb) {
                 const double* Wr = fc + (c0 + r128) + (size_t)f * c0;
                 for (int c = g8; c <= r128; c += 8) acc = __builtin_fma(Wr[(size_t)f * c], wf[c0 + c], acc);
             }
             part[g8 * HB2_NB + r128] = acc;
-        }
-        __syncthreads();
-        if (tid < nb) {
-            double s = 0.0;
+            __syncthreads();
+            if (tid < nb) {
+                double s = 0.0;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
-            wf[c0 + tid] = s;
-            yo[px[c0 + tid]] = s;
+                for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+                wf[c0 + tid] = s;
+                yo[px[c0 + tid]] = s;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // rows below the diagonal block: wf[r] -= sum_c L(r, c0 + c) y[c]; 128 rows x 8 column groups per pass
         const int rend = split ? p : f;
         for (int R0 = c0 + nb; R0 < rend; R0 += HB2_NB) {
@@ -680,7 +925,7 @@ __global__ __launch_bounds__(NDL_T) void nd_bwd_cols_kernel(NdSolveArgs A) {
     double* yo = A.y + (size_t)img * A.n;
     for (int i = tid; i < b; i += NDL_T) sm[i] = x[px[p + i]];
     __syncthreads();
-    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* fc = (A.lu ? A.fac2 : A.fac) + (size_t)img * A.fac_stride + v.fac_off;
     const int nb = min(HB2_NB, p - c0);
     for (int c = wave; c < nb; c += NDL_T / 64) {
         const double* col = fc + p + (size_t)f * (c0 + c);
@@ -709,7 +954,7 @@ __global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A, int 
     if (!split)
         for (int i = tid; i < b; i += NDL_T) vf[p + i] = x[px[p + i]];
     __syncthreads();
-    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* fc = (A.lu ? A.fac2 : A.fac) + (size_t)img * A.fac_stride + v.fac_off;
     double* ac = A.acc ? A.acc + (size_t)img * A.n : nullptr;
     const int npan = (p + HB2_NB - 1) / HB2_NB;
     const int rend = split ? p : f;
@@ -730,7 +975,7 @@ __global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A, int 
             double acc = 0.0;
             if (c < nb) {
                 const double* Wc = fc + c0 + (size_t)f * (c0 + c);
-                for (int r = c + g8; r < nb; r += 8) acc = __builtin_fma(Wc[r], tt[r], acc);
+                for (int r = (A.lu ? 0 : c) + g8; r < nb; r += 8) acc = __builtin_fma(Wc[r], tt[r], acc);
             }
             part[g8 * HB2_NB + c] = acc;
         }

@@ -34,6 +34,8 @@ struct NdSolver {
     int *d_pix = nullptr, *d_cmap = nullptr, *d_inv = nullptr;
     int4* d_orig = nullptr;
     double *fac = nullptr, *ws[2] = {nullptr, nullptr}, *yv = nullptr, *uv = nullptr;
+    bool lu = false;                   // LU variant (nd_kernels.hpp): the fronts' upper triangles, transposed, beside the lower
+    double *facU = nullptr, *wsU[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
     std::string err;
     double factor_flop = 0.0;          // per image (multiply-add = 2)
@@ -55,15 +57,17 @@ struct NdSolver {
 
     // bytes of device memory per image of the workspace (factor, two update-matrix workspaces, vectors)
     size_t bytes_per_image() const {
-        return sizeof(double) * (size_t)(T.fac_doubles + T.ws_doubles[0] + T.ws_doubles[1] + T.uv_doubles + T.n);
+        return sizeof(double) * (size_t)((lu ? 2 : 1) * (T.fac_doubles + T.ws_doubles[0] + T.ws_doubles[1]) + T.uv_doubles + T.n);
     }
     size_t index_bytes() const {
         return sizeof(NdNodeDev) * T.nodes.size() + sizeof(int) * (T.pix.size() + T.cmap.size()) + sizeof(int4) * T.orig.size();
     }
 
     // symbolic phase + upload of the index arrays.  Returns 0, 2 (HIP error) or 5 (out of memory).
-    int build(int M, int N, const NdStencil& st, int leaf_pix = 0) {
+    // lu_variant: block LU without pivoting for a structurally symmetric, numerically non-symmetric matrix.
+    int build(int M, int N, const NdStencil& st, int leaf_pix = 0, bool lu_variant = false) {
         release();
+        lu = lu_variant;
         T = nd_build(M, N, st, leaf_pix > 0 ? leaf_pix : default_leaf());
         factor_flop = 2.0 * T.flops();
         const int L = T.levels();
@@ -124,6 +128,10 @@ struct NdSolver {
                                   (int)nd_small_lds(128)));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bcr_potrf_lds(HB2_NB)));
+        NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_small_lu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)nd_small_lds(128)));
+        NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_getri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)nd_getri_lds()));
         if (nd_large_lds(T.max_f) > 160 * 1024) { err = "front too large for the substitution kernels"; return 6; }
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_fwd_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)nd_large_lds(T.max_f)));
@@ -147,13 +155,17 @@ struct NdSolver {
         for (int s = 0; s < 2; ++s) NDCHK(hipMalloc((void**)&ws[s], std::max<size_t>(1, (size_t)nimg * T.ws_doubles[s]) * sizeof(double)));
         NDCHK(hipMalloc((void**)&yv, (size_t)nimg * T.n * sizeof(double)));
         NDCHK(hipMalloc((void**)&uv, std::max<size_t>(1, (size_t)nimg * T.uv_doubles) * sizeof(double)));
+        if (lu) {
+            NDCHK(hipMalloc((void**)&facU, (size_t)nimg * T.fac_doubles * sizeof(double)));
+            for (int s = 0; s < 2; ++s) NDCHK(hipMalloc((void**)&wsU[s], std::max<size_t>(1, (size_t)nimg * T.ws_doubles[s]) * sizeof(double)));
+        }
         cap = nimg;
         return 0;
     }
     void free_ws() {
-        for (void* p : {(void*)fac, (void*)ws[0], (void*)ws[1], (void*)yv, (void*)uv})
+        for (void* p : {(void*)fac, (void*)ws[0], (void*)ws[1], (void*)yv, (void*)uv, (void*)facU, (void*)wsU[0], (void*)wsU[1]})
             if (p) (void)hipFree(p);
-        fac = ws[0] = ws[1] = yv = uv = nullptr;
+        fac = ws[0] = ws[1] = yv = uv = facU = wsU[0] = wsU[1] = nullptr;
         cap = 0;
     }
     void release() {
@@ -170,8 +182,10 @@ struct NdSolver {
         if (!built || nimg > cap) { err = "nd solver: not built or workspace too small"; return 2; }
         NdArgs A;
         A.nodes = d_nodes; A.pix = d_pix; A.cmap = d_cmap; A.orig = d_orig; A.inv = d_inv;
-        A.planes = planes; A.tot = tot; A.n = T.n;
-        A.fac = fac; A.fac_stride = T.fac_doubles; A.fail = d_fail;
+        if (lu) { err = "nd solver: built for LU, use factor_lu"; return 2; }
+        A.planes = planes; A.planes2 = planes; A.tot = tot; A.n = T.n;
+        A.fac = fac; A.fac2 = fac; A.fac_stride = T.fac_doubles; A.fail = d_fail;
+        A.ws_mine2 = nullptr; A.ws_child2 = nullptr;
         const int L = T.levels();
         for (int l = L - 1; l >= 0; --l) {
             const Level& a = lv[l];
@@ -195,7 +209,7 @@ struct NdSolver {
                     hipLaunchKernelGGL(nd_potrf_kernel, dim3(qn, nimg), dim3(BCR_PT), bcr_potrf_lds(std::min(HB2_NB, nd_up16(a.pmax - HB2_NB * k))), stream, A, k);
                     const int below = a.fmax - HB2_NB * k;
                     const int ntile = (below + 63) / 64;
-                    if (ntile > 0) hipLaunchKernelGGL(nd_trsm_kernel, dim3(ntile, qn, nimg), dim3(BG_T), 0, stream, A, k);
+                    if (ntile > 0) hipLaunchKernelGGL(nd_trsm_kernel, dim3(ntile, qn, nimg), dim3(BG_T), 0, stream, A, k, 0);
                     if (a.pmax > HB2_NB * (k + 1)) {
                         const int ntr = (a.fmax - HB2_NB * (k + 1) + 63) / 64;
                         hipLaunchKernelGGL(nd_syrk_kernel, dim3(ntr * (ntr + 1) / 2, qn, nimg), dim3(BG_T), 0, stream, A, k);
@@ -211,11 +225,69 @@ struct NdSolver {
         return 0;
     }
 
+    // LU variant.  planesL: diagonals of the lower triangle (A[c + off][c] at pixel c, plane 0 = main diagonal), planesU: of the
+    // upper triangle (A[c][c + off] at pixel c; its plane 0 is not read).  d_fail[img]: node + 1 of the first broken pivot.
+    int factor_lu(const double* planesL, const double* planesU, size_t tot, int nimg, int* d_fail) {
+        if (!built || !lu || nimg > cap) { err = "nd solver: not built for LU or workspace too small"; return 2; }
+        const int L = T.levels();
+        for (int l = L - 1; l >= 0; --l) {
+            const Level& a = lv[l];
+            // side 0 writes the lower triangles (FL, update matrices' lower parts), side 1 the transposed upper ones
+            auto args = [&](int side) {
+                NdArgs A;
+                A.nodes = d_nodes; A.pix = d_pix; A.cmap = d_cmap; A.orig = d_orig; A.inv = d_inv;
+                A.planes = side ? planesU : planesL; A.planes2 = side ? planesL : planesU; A.tot = tot; A.n = T.n;
+                A.fac = side ? facU : fac; A.fac2 = side ? fac : facU; A.fac_stride = T.fac_doubles; A.fail = d_fail;
+                double* const* wm = side ? wsU : ws;
+                double* const* wo = side ? ws : wsU;
+                A.ws_mine = wm[l & 1]; A.ws_mine_stride = T.ws_doubles[l & 1];
+                A.ws_child = wm[(l + 1) & 1]; A.ws_child_stride = T.ws_doubles[(l + 1) & 1];
+                A.ws_mine2 = wo[l & 1]; A.ws_child2 = wo[(l + 1) & 1];
+                A.node0 = a.n0;
+                return A;
+            };
+            const int cnt = a.n1 - a.n0;
+            if (a.small) {
+                hipLaunchKernelGGL(nd_front_small_lu_kernel, dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, args(0));
+                continue;
+            }
+            for (int q0 = a.n0; q0 < a.n1; q0 += 32768) {
+                const int qn = std::min(32768, a.n1 - q0);
+                NdArgs AL = args(0), AU = args(1);
+                AL.node0 = AU.node0 = q0;
+                const dim3 gg(std::max(1, std::min((a.fmax + 3) / 4, 128)), qn, nimg);
+                hipLaunchKernelGGL(nd_gather_kernel, gg, dim3(256), 0, stream, AL);
+                hipLaunchKernelGGL(nd_gather_kernel, gg, dim3(256), 0, stream, AU);
+                hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, AL);
+                hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, AU);
+                const int npan = (a.pmax + HB2_NB - 1) / HB2_NB;
+                for (int k = 0; k < npan; ++k) {
+                    hipLaunchKernelGGL(nd_getri_kernel, dim3(qn, nimg), dim3(NDG_T), nd_getri_lds(), stream, AL, k);
+                    const int below = a.fmax - HB2_NB * k;
+                    const int ntile = (below + 63) / 64;
+                    if (ntile > 0) hipLaunchKernelGGL(nd_trsm_kernel, dim3(ntile, qn, nimg), dim3(BG_T), 0, stream, AL, k, 1);
+                    if (a.pmax > HB2_NB * (k + 1)) {
+                        const int ntr = (a.fmax - HB2_NB * (k + 1) + 63) / 64;
+                        hipLaunchKernelGGL(nd_syrk_kernel, dim3(ntr * (ntr + 1) / 2, qn, nimg), dim3(BG_T), 0, stream, AL, k);
+                        hipLaunchKernelGGL(nd_syrk_kernel, dim3(ntr * (ntr + 1) / 2, qn, nimg), dim3(BG_T), 0, stream, AU, k);
+                    }
+                }
+                if (a.bmax > 0) {
+                    const int nt = (a.bmax + 63) / 64;
+                    hipLaunchKernelGGL(nd_schur_kernel, dim3(nt * (nt + 1) / 2, qn, nimg), dim3(BG_T), 0, stream, AL);
+                    hipLaunchKernelGGL(nd_schur_kernel, dim3(nt * (nt + 1) / 2, qn, nimg), dim3(BG_T), 0, stream, AU);
+                }
+            }
+        }
+        NDCHK(hipGetLastError());
+        return 0;
+    }
+
     // vec <- A^-1 vec for `nimg` images ([nimg][n]); acc += solution when not null.
     int solve(double* vec, double* acc, int nimg) {
         if (!built || nimg > cap) { err = "nd solver: not built or workspace too small"; return 2; }
         NdSolveArgs S;
-        S.nodes = d_nodes; S.pix = d_pix; S.cmap = d_cmap; S.fac = fac; S.fac_stride = T.fac_doubles;
+        S.nodes = d_nodes; S.pix = d_pix; S.cmap = d_cmap; S.fac = fac; S.fac2 = lu ? facU : fac; S.lu = lu ? 1 : 0; S.fac_stride = T.fac_doubles;
         S.vec = vec; S.y = yv; S.uv = uv; S.uv_stride = T.uv_doubles; S.acc = nullptr; S.n = T.n;
         const int L = T.levels();
         for (int l = L - 1; l >= 0; --l) {

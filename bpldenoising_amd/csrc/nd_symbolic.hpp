@@ -57,7 +57,12 @@ struct NdNode {
     int64_t u_off = 0;                    // doubles: update matrix (b x b, leading dimension b) in its level's workspace
     int64_t uv_off = 0;                   // doubles: update vector (b) of the substitutions, all levels in one array
 };
-struct NdOrig { int r, c, plane, pixel; };   // F(r, c) += planes[plane][pixel], r >= c front-local
+// F(r, c) += planes[plane & 15][pixel], r >= c front-local.  Bit ND_ORIG_UPPER of `plane` says that the entry F(r, c) =
+// A[g_r][g_c] has the smaller pixel as its ROW (g_r < g_c: an entry of A's upper triangle, stored at pixel g_r) -- the
+// same number for a symmetric matrix; the LU variant (nd_solver.hpp, lu = true) reads it from the upper diagonals, and
+// the mirror entry F(c, r) from the other set.
+constexpr int ND_ORIG_UPPER = 16;
+struct NdOrig { int r, c, plane, pixel; };
 
 struct NdTree {
     int M = 0, N = 0, n = 0;
@@ -207,7 +212,7 @@ inline NdTree nd_build(int M, int N, const NdStencil& st, int leaf_pix = 32) {
                     const int k2 = pos[g2];                          // in this front by construction
                     if (k2 < 0 || k2 >= f || T.pix[v.piv_off + k2] != g2) abort();
                     // plane s stores A[c + off][c] at the pixel of smaller linear index
-                    T.orig.push_back({k2, k, s, sg > 0 ? g : g2});
+                    T.orig.push_back({k2, k, sg > 0 ? s : (s | ND_ORIG_UPPER), sg > 0 ? g : g2});
                 }
         }
         v.orig_cnt = (int)T.orig.size() - v.orig_off;

@@ -128,7 +128,8 @@ typedef struct bpltv_stats {
                                   weight was reduced by 1e-2 per retry after a non-positive pivot      */
     int adjoint_method;        /* 1 banded Cholesky (LDS window), 2 block cyclic reduction,
                                   3 banded Cholesky (HBM band), 4 banded LU (sum of regularisers, row-scaled
-                                  gradient_reg system), 5 nested-dissection (multifrontal) Cholesky      */
+                                  gradient_reg system, with reserved[4] = 1), 5 nested-dissection (multifrontal)
+                                  Cholesky, 6 nested-dissection LU (that row-scaled system, the default)  */
     int reg_gradient_used;     /* 1 if the last evaluate took the gradient_reg branch             */
     int ngpus;                 /* distinct devices behind this handle (1 for bpltv_create)        */
     int shards;                /* image shards (= worker threads) behind this handle              */

@@ -70,12 +70,14 @@ def test_evaluate_matches_oracle(gpu_solver_cls, oracle, alpha):
         _, _, greg = s.sumregs_evaluate(alpha, 1e-4, maxiter=1500)
         assert s.stats()["reg_gradient_used"] == 1
         assert np.allclose(greg, oracle.sumregs_gradient(alpha, u0, ub, reg=True), rtol=1e-7)
-    else:                       # patch parameter: the row-scaled system is not symmetric -> banded LU path
+    else:                       # patch parameter: the row-scaled system is not symmetric -> LU variant of the nested dissection
         _, _, greg = s.sumregs_evaluate(alpha, 1e-4, maxiter=1500)
         st = s.stats()
-        assert st["reg_gradient_used"] == 1 and st["adjoint_residual"] <= 1e-8
+        assert st["reg_gradient_used"] == 1 and st["adjoint_residual"] <= 1e-8 and st["adjoint_method"] == "nd-lu"
         g1 = oracle.sumregs_gradient(alpha, u0, ub, reg=True)
         assert np.abs(greg - g1).max() <= 1e-7 * np.abs(g1).max()
+        _, _, gband = s.sumregs_evaluate(alpha, 1e-4, maxiter=1500, adjoint_method="band")    # cross-check: banded LU
+        assert s.stats()["adjoint_method"] == "band-lu" and np.abs(gband - greg).max() <= 1e-9 * np.abs(g1).max()
     s.close()
 
 

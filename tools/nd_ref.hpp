@@ -30,7 +30,7 @@ inline Factor factor(const NdTree& T, const std::vector<std::vector<double>>& pl
             std::vector<double> A((size_t)f * f, 0.0);   // column major, lower triangle
             for (int e = 0; e < v.orig_cnt; ++e) {
                 const NdOrig& o = T.orig[v.orig_off + e];
-                A[o.r + (size_t)f * o.c] += planes[o.plane][o.pixel];
+                A[o.r + (size_t)f * o.c] += planes[o.plane & 15][o.pixel];
             }
             for (int ci = 0; ci < 2; ++ci) {
                 if (v.child[ci] < 0) continue;

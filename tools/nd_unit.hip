@@ -1,7 +1,8 @@
 // nd_unit.hip -- unit checks of the nested-dissection Cholesky (csrc/nd_solver.hpp, nd_kernels.hpp) against the host
 // restatement tools/nd_ref.hpp: factor entries (W = L11^-1, L21 of every front) and solutions on random SPD stencil
 // matrices, several images per call, both stencils, shapes with small-regime levels only and with large-regime
-// levels (multi-panel pivot blocks).  `nd_unit time M nimg [sr]` times factor and solve on an M x M grid.
+// levels (multi-panel pivot blocks); the LU variant on random non-symmetric stencil matrices (solutions).
+// `nd_unit time M nimg [sr]` times factor and solve on an M x M grid.
 // tests/test_gpu_evaluate.py::test_nd_solver_unit_checks runs it.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -105,6 +106,97 @@ static int check(int M, int N, bool sr, int leaf, int nimg, double big) {
     return ok ? 0 : 1;
 }
 
+// LU variant: random row-diagonally-dominant NON-symmetric stencil matrices (independent lower and upper diagonals, a few
+// strongly coupled pairs), solution against the vector the right-hand side was made from.
+static int check_lu(int M, int N, bool sr, int leaf, int nimg, double big) {
+    NdSolver S;
+    const NdStencil st = sr ? nd_stencil_sr() : nd_stencil_tv();
+    if (S.build(M, N, st, leaf, true)) { printf("build failed: %s\n", S.err.c_str()); return 1; }
+    hipStream_t stream;
+    CK(hipStreamCreate(&stream));
+    if (S.alloc(nimg, stream)) { printf("alloc failed: %s\n", S.err.c_str()); return 1; }
+    const NdTree& T = S.T;
+    const int n = T.n, nd = st.nd;
+    const size_t tot = (size_t)nimg * n;
+    std::vector<double> pl((size_t)nd * tot, 0.0), pu((size_t)nd * tot, 0.0), rhs(tot, 0.0), xt(tot);
+    unsigned long long rs = 1234567 + 31 * M + N;
+    auto rnd = [&]() {
+        rs = rs * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)((rs >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53);
+    };
+    for (int k = 0; k < nimg; ++k) {
+        double* L = &pl[(size_t)k * n];
+        double* U = &pu[(size_t)k * n];
+        std::vector<double> rowsum(n, 0.0);
+        for (int t = 1; t < nd; ++t)
+            for (int g = 0; g < n; ++g) {
+                const int i = g % M, j = g / M, a = i + st.di[t], c = j + st.dj[t];
+                if (a < 0 || a >= M || c < 0 || c >= N) continue;
+                const int g2 = a + M * c;   // g2 > g
+                double vl = -(0.1 + rnd()), vu = -(0.1 + rnd());
+                if (big > 0.0 && rnd() < 0.2) { vl *= big; vu *= big * (0.5 + rnd()); }
+                L[(size_t)t * tot + g] = vl;   // A[g2][g]
+                U[(size_t)t * tot + g] = vu;   // A[g][g2]
+                rowsum[g2] += std::fabs(vl);
+                rowsum[g] += std::fabs(vu);
+            }
+        for (int g = 0; g < n; ++g) L[g] = rowsum[g] + 1.0 + rnd();
+        for (int g = 0; g < n; ++g) xt[(size_t)k * n + g] = std::sin(0.37 * g + k) + 0.1 * (g % 7);
+        const double* x = &xt[(size_t)k * n];
+        double* y = &rhs[(size_t)k * n];
+        for (int g = 0; g < n; ++g) y[g] = L[g] * x[g];
+        for (int t = 1; t < nd; ++t)
+            for (int g = 0; g < n; ++g) {
+                const int i = g % M, j = g / M, a = i + st.di[t], c = j + st.dj[t];
+                if (a < 0 || a >= M || c < 0 || c >= N) continue;
+                const int g2 = a + M * c;
+                y[g2] += L[(size_t)t * tot + g] * x[g];
+                y[g] += U[(size_t)t * tot + g] * x[g2];
+            }
+    }
+    double *d_pl, *d_pu, *d_vec, *d_acc;
+    int* d_fail;
+    CK(hipMalloc((void**)&d_pl, pl.size() * sizeof(double)));
+    CK(hipMalloc((void**)&d_pu, pu.size() * sizeof(double)));
+    CK(hipMalloc((void**)&d_vec, tot * sizeof(double)));
+    CK(hipMalloc((void**)&d_acc, tot * sizeof(double)));
+    CK(hipMalloc((void**)&d_fail, nimg * sizeof(int)));
+    CK(hipMemcpy(d_pl, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pu, pu.data(), pu.size() * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_vec, rhs.data(), tot * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemset(d_acc, 0, tot * sizeof(double)));
+    CK(hipMemset(d_fail, 0, nimg * sizeof(int)));
+    if (S.factor_lu(d_pl, d_pu, tot, nimg, d_fail)) { printf("factor failed: %s\n", S.err.c_str()); return 1; }
+    if (S.solve(d_vec, d_acc, nimg)) { printf("solve failed: %s\n", S.err.c_str()); return 1; }
+    CK(hipStreamSynchronize(stream));
+    std::vector<int> fail(nimg);
+    std::vector<double> x(tot), acc(tot);
+    CK(hipMemcpy(fail.data(), d_fail, nimg * sizeof(int), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(x.data(), d_vec, tot * sizeof(double), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(acc.data(), d_acc, tot * sizeof(double), hipMemcpyDeviceToHost));
+    int bad = 0, nsmall = 0, nlarge = 0;
+    for (const auto& a : S.lv) (a.small ? nsmall : nlarge)++;
+    double worst = 0.0;
+    for (int k = 0; k < nimg; ++k) {
+        if (fail[k]) { printf("  image %d: pivot failure at node %d\n", k, fail[k] - 1); ++bad; continue; }
+        double err = 0.0, nrm = 0.0;
+        for (int g = 0; g < n; ++g) {
+            const double xv = x[(size_t)k * n + g];
+            err = std::fmax(err, std::fabs(xv - xt[(size_t)k * n + g]));
+            nrm = std::fmax(nrm, std::fabs(xt[(size_t)k * n + g]));
+            if (xv != xv || acc[(size_t)k * n + g] != xv) err = 1e300;
+        }
+        worst = std::fmax(worst, err / nrm);
+    }
+    const bool ok = bad == 0 && worst <= 1e-8;
+    printf("%s LU %4dx%-4d %s leaf %3d x%d images, %zu fronts, %d levels (%d small, %d large), max front %d: solution %.1e\n", ok ? "ok  " : "FAIL", M, N,
+           sr ? "sr" : "tv", leaf, nimg, T.nodes.size(), T.levels(), nsmall, nlarge, T.max_f, worst);
+    S.release();
+    CK(hipFree(d_pl)); CK(hipFree(d_pu)); CK(hipFree(d_vec)); CK(hipFree(d_acc)); CK(hipFree(d_fail));
+    CK(hipStreamDestroy(stream));
+    return ok ? 0 : 1;
+}
+
 static int timing(int M, int nimg, bool sr, int leaf) {
     NdSolver S;
     const NdStencil st = sr ? nd_stencil_sr() : nd_stencil_tv();
@@ -189,6 +281,15 @@ int main(int argc, char** argv) {
     bad += check(300, 260, false, 16, 2, 1e6);      // two pivot panels (root separator 300 > 256: three)
     bad += check(200, 180, true, 32, 2, 1e4);       // separators of width 2: pivot blocks up to 400
     bad += check(7, 500, false, 32, 2, 1e6);
+    bad += check_lu(1, 1, true, 32, 2, 0.0);
+    bad += check_lu(5, 4, false, 1, 2, 0.0);
+    bad += check_lu(33, 17, true, 8, 2, 1e6);
+    bad += check_lu(40, 64, false, 32, 3, 1e6);     // small regime only
+    bad += check_lu(96, 50, true, 32, 2, 1e6);
+    bad += check_lu(128, 128, true, 32, 3, 1e6);    // the shape of the reference's batches
+    bad += check_lu(150, 139, false, 32, 2, 1e6);
+    bad += check_lu(200, 180, true, 32, 2, 1e4);    // pivot blocks of several panels
+    bad += check_lu(7, 500, true, 32, 2, 1e6);
     printf(bad ? "nd_unit: %d FAILED\n" : "nd_unit: all ok\n", bad);
     return bad ? 1 : 0;
 }
