@@ -45,6 +45,7 @@ struct Variant {
     const void* func32;
     size_t lds32;
     int tiles_per_block;   // 1: one workgroup per tile (pdhg_tile_kernel); > 1: that many one-wave tiles per workgroup
+    int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel)
 };
 
 template <typename T, int PI, int PJ, int TI, int TJ>
@@ -59,7 +60,7 @@ void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       pdhg_lds_bytes(PI * TI, PJ * TJ), #PI "x" #PJ "px_" #TI "x" #TJ "thr",                    \
       &launch_variant<float, PI, PJ, TI, TJ>,                                                   \
       reinterpret_cast<const void*>(&pdhg_tile_kernel<float, PI, PJ, TI, TJ>),                  \
-      pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(float)), 1 }
+      pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(float)), 1, 0 }
 // register tiles: one wave per 32 x (2 PJ) region, WPB waves per workgroup (pdhg_wave_kernel)
 template <typename T, int PJ, int WPB>
 void launch_wave_variant(const PdhgArgs& a, int grid, hipStream_t s) {
@@ -69,7 +70,17 @@ void launch_wave_variant(const PdhgArgs& a, int grid, hipStream_t s) {
     { 32, 2 * PJ, 64 * WPB, &launch_wave_variant<double, PJ, WPB>,                              \
       reinterpret_cast<const void*>(&pdhg_wave_kernel<double, PJ, WPB>), 0, "wave_32x" #PJ "x2",  \
       &launch_wave_variant<float, PJ, WPB>,                                                     \
-      reinterpret_cast<const void*>(&pdhg_wave_kernel<float, PJ, WPB>), 0, WPB }
+      reinterpret_cast<const void*>(&pdhg_wave_kernel<float, PJ, WPB>), 0, WPB, 0 }
+// 64-lane rows, PJ pixels per thread along j, TJ waves (pdhg_rows_kernel): region 64 x (PJ * TJ); CL: f and alpha in LDS
+template <typename T, int PJ, int TJ, bool CL>
+void launch_rows_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pdhg_rows_kernel<T, PJ, TJ, CL>), dim3(grid), dim3(64 * TJ), pdhg_rows_lds(PJ, TJ, CL, sizeof(T)), s, a);
+}
+#define VARR(PJ, TJ, CL)                                                                        \
+    { 64, PJ * TJ, 64 * TJ, &launch_rows_variant<double, PJ, TJ, CL>,                           \
+      reinterpret_cast<const void*>(&pdhg_rows_kernel<double, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL),  \
+      "rows_64x" #PJ "px_" #TJ "waves" #CL, &launch_rows_variant<float, PJ, TJ, CL>,            \
+      reinterpret_cast<const void*>(&pdhg_rows_kernel<float, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL, sizeof(float)), 1, 1 }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
@@ -89,6 +100,17 @@ const Variant kVariants[] = {
     VARW(16, 4),        // 16: register tiles, one wave per 32x32 region (16 px per lane), no LDS, no barriers
     VARW(8, 4),         // 17: ... per 32x16 region (8 px per lane)
     VARW(12, 4),        // 18: ... per 32x24 region (12 px per lane)
+    VARR(8, 8, false),  // 19: 64-lane rows, 64x64 region, 8 px per thread, 512 threads
+    VARR(6, 8, false),  // 20: ... 64x48 region, 6 px per thread
+    VARR(8, 16, false), // 21: ... 64x128 region, 8 px per thread, 1024 threads
+    VARR(4, 16, false), // 22: ... 64x64 region, 4 px per thread, 1024 threads
+    VARR(6, 16, false), // 23: ... 64x96 region, 6 px per thread, 1024 threads
+    VARR(8, 8, true),   // 24: as 19 with f and alpha in LDS
+    VARR(6, 8, true),   // 25: as 20 ...
+    VARR(10, 8, true),  // 26: 64x80 region, 10 px per thread, 512 threads
+    VARR(12, 8, true),  // 27: 64x96 region, 12 px per thread, 512 threads
+    VARR(12, 4, true),  // 28: 64x48 region, 12 px per thread, 256 threads
+    VARR(16, 4, true),  // 29: 64x64 region, 16 px per thread, 256 threads
     // (64x36 / 3 px and 64x48 / 4 px with 64-thread rows -- whole halo waves that stop early -- were measured too: 86
     //  resp. 110 VGPRs, one workgroup per CU, 1.88e4 / 2.14e4 it/s on 8 x 1024^2 against 2.55e4 for variant 13)
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
@@ -444,6 +466,11 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
                 if (cost < best) { best = cost; T = t; v = cd.v; }
             }
         }
+    }
+    if (kVariants[v].min_image && (M < kVariants[v].RI || N < kVariants[v].RJ)) {
+        if (!auto_variant)
+            return set_err(h, BPLTV_E_ARG, "kernel variant %d needs an image of at least %dx%d pixels", v + 1, kVariants[v].RI, kVariants[v].RJ);
+        v = 12;
     }
     const Variant& V = kVariants[v];
     if (T <= 0) {

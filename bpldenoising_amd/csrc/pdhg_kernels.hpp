@@ -439,6 +439,191 @@ __device__ __forceinline__ double pd_lane_next(double v) {
 __device__ __forceinline__ float pd_lane_prev(float v) { return __int_as_float(pd_dpp_prev(__float_as_int(v))); }
 __device__ __forceinline__ float pd_lane_next(float v) { return __int_as_float(pd_dpp_next(__float_as_int(v))); }
 
+// lane - 1 with 0 for lane 0 (bound_ctrl: no previous value to keep, no move to set it up); lane + 1 with the lane's own
+// value for lane 63 (bound_ctrl off: the destination keeps `v`)
+__device__ __forceinline__ double pd_lane_prev_or0(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double pd_lane_next_or_self(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_lane_prev_or0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float pd_lane_next_or_self(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+// ------------------------------------------------------------------------------------------
+// pdhg_rows_kernel: the fused iteration of pdhg_tile_kernel for LARGE images, laid out so that the halo costs less.
+//
+// A wave is one row of 64 threads along i; a thread owns PJ consecutive pixels along j (lj = PJ * tj + pj): region
+// 64 x (PJ * TJ), TJ waves.  Neighbours along i are the adjacent lanes (DPP wave shifts, no LDS), neighbours along j
+// inside a thread's strip are its own registers; only a strip's ends go through LDS (two planes of TJ + 1 rows: the y2
+// of a strip's last pixel, the xbar of its first) -- 1 / PJ of pdhg_tile_kernel's LDS traffic, 2 KB instead of 55 KB,
+// so occupancy is set by registers alone.  What that buys:
+//   * 64 x 64 at T = 8 recomputes 1.78 x instead of the 2.25 x of the 48 x 48 region;
+//   * halo pixels stop when nobody reads them any more (pdhg_tile_kernel does that per wave; here a wave's PJ pixel rows
+//     are stopped row by row under wave-uniform branches): the first and last wave of a 64 x 64 region skip half their
+//     pixel-iterations, 1.56 x recompute in all.
+// Same arithmetic per pixel as pdhg_tile_kernel: bit-identical results.  Block 64 * TJ, dynamic LDS pdhg_rows_lds.
+// For images of at least 64 x (PJ * TJ) pixels only (the host checks): then the image's last row / column is the region's
+// last lane / pixel row (tile_span), where the Neumann difference xbar - xbar = +0 comes from the lane shift keeping the
+// own value and from one select per strip -- no per-pixel border selects in the loop.
+// ------------------------------------------------------------------------------------------
+// CL: the per-pixel constants f and alpha live in LDS (each thread's own cells, read back every iteration) instead of
+// registers -- 4 VGPRs per pixel less, which is what lets two 8-pixel workgroups share a CU.
+constexpr size_t pdhg_rows_lds(int PJ, int TJ, bool CL, size_t word = sizeof(double)) {
+    return word * 64 * (2 * (size_t)(TJ + 1) + (CL ? 2 * (size_t)PJ * TJ : 0));
+}
+
+template <typename T, int PJ, int TJ, bool CL>
+__global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
+    constexpr int RI = 64, RJ = PJ * TJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pdhg_smem[];
+    T* sy2 = reinterpret_cast<T*>(pdhg_smem);   // [TJ + 1][64]: row tj + 1 = y2 of strip tj's last pixel row, row 0 = 0
+    T* sxb = sy2 + (TJ + 1) * 64;               // [TJ + 1][64]: row tj = xbar of strip tj's first pixel row, row TJ = 0
+    T* sfc = sxb + (TJ + 1) * 64;               // CL: [RJ][64] f, then [RJ][64] alpha
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
+    const int tid = threadIdx.x, ti = tid & 63;
+    const int tj = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: uniform
+    const int tilesPerImg = A.nTi * A.nTj;
+    const int imgl = blockIdx.x / tilesPerImg;
+    const int img = A.img0 + imgl;
+    const int t = blockIdx.x - imgl * tilesPerImg;
+    const int ta = t % A.nTi, tb = t / A.nTi;
+    int oi, ci0, ci1, oj, cj0, cj1;
+    tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
+    tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
+    const int M = A.M, N = A.N;
+    const size_t base = (size_t)img * M * N;
+    const size_t fbase = (size_t)(img % A.Odata) * M * N;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)(img / A.Odata) * A.astride;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const bool first = A.first != 0;
+    const int lj0 = PJ * tj;
+    const int gi = min(oi + ti, M - 1);
+    const bool in_i = oi + ti < M;
+
+    T x[PJ], y1[PJ], y2[PJ], f[PJ], al[PJ];
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = min(oj + lj0 + pj, N - 1);
+        const size_t gidx = gi + (size_t)M * gj;
+        size_t ai = 0;
+        if (amode == 2) ai = gidx;
+        else if (amode == 1) ai = ((unsigned)gi * (unsigned)A.am) / (unsigned)M + (size_t)A.am * (((unsigned)gj * (unsigned)A.an) / (unsigned)N);
+        if (!first) {
+            x[pj] = Axin[base + gidx];
+            y1[pj] = Ay1in[base + gidx];
+            y2[pj] = Ay2in[base + gidx];
+        }
+        f[pj] = Af[fbase + gidx];
+        al[pj] = alpha[ai];
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        if (first) { x[pj] = f[pj]; y1[pj] = T(0); y2[pj] = T(0); }
+        if (!(in_i && oj + lj0 + pj < N)) { f[pj] = T(0); x[pj] = T(0); y1[pj] = T(0); y2[pj] = T(0); al[pj] = T(0); }
+        if (CL) {
+            sfc[(lj0 + pj) * 64 + ti] = f[pj];
+            sfc[(RJ + lj0 + pj) * 64 + ti] = al[pj];
+        }
+    }
+    sy2[(tj + 1) * 64 + ti] = y2[PJ - 1];
+    if (tj == 0) { sy2[ti] = T(0); sxb[TJ * 64 + ti] = T(0); }
+    __syncthreads();
+
+    const T rho = (T)A.rho;
+    const int nit = A.nit;
+    const bool hasD_last = oj + lj0 + PJ - 1 < N - 1;
+    // iterations pixel row lj is still read for: lj of them next to a near edge that is not the image border, RJ - lj
+    // next to such a far edge (see pdhg_tile_kernel)
+    int lim[PJ];
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int lj = lj0 + pj;
+        int l = nit;
+        if (oj > 0) l = min(l, lj);
+        if (oj + RJ < N) l = min(l, RJ - lj);
+        lim[pj] = l;
+    }
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
+    T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    for (int it = 0; it < nit; ++it) {
+        const T* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
+        const T ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        T xb[PJ];
+        // ---- primal step
+        const T y2up = sy2[tj * 64 + ti];   // y2 of the pixel row above the strip (guard row of zeros at lj = 0)
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            xb[pj] = T(0);
+            if (it < lim[pj]) {
+                const T y1m = pd_lane_prev_or0(y1[pj]);                // lane 0: the zero guard column
+                const T y2m = (pj > 0) ? y2[pj > 0 ? pj - 1 : 0] : y2up;
+                const T div = (y1m - y1[pj]) + (y2m - y2[pj]);
+                const T tt = div - (CL ? sfc[(lj0 + pj) * 64 + ti] : f[pj]);
+                const T xo = x[pj];
+                const T xn = pd_fma(-tau, tt, xo) * inv1ptau;
+                xb[pj] = pd_fma(-omega, xo, opw * xn);
+                x[pj] = xn;
+            }
+        }
+        sxb[tj * 64 + ti] = xb[0];
+        __syncthreads();
+        // ---- dual step
+        const T xbdn = sxb[(tj + 1) * 64 + ti];   // xbar of the pixel row below the strip
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            if (it < lim[pj]) {
+                const T b = xb[pj];
+                const T xp1 = pd_lane_next_or_self(b);                 // lane 63: own value
+                const T xpM = (pj < PJ - 1) ? xb[pj < PJ - 1 ? pj + 1 : pj] : (hasD_last ? xbdn : b);
+                const T d1 = xp1 - b;
+                const T d2 = xpM - b;
+                const T a = CL ? sfc[(RJ + lj0 + pj) * 64 + ti] : al[pj];
+                T y1n = pd_fma(sigma, d1, y1[pj]);
+                T y2n = pd_fma(sigma, d2, y2[pj]);
+                if (rho != T(0)) {
+                    const T den = T(1) + sigma * rho / a;
+                    y1n = y1n / den;
+                    y2n = y2n / den;
+                }
+                const T n2v = pd_fma(y2n, y2n, y1n * y1n);
+                if (n2v > a * a) {
+                    const T v = a * rsqrt_nr(n2v);
+                    y1n = y1n * v;
+                    y2n = y2n * v;
+                }
+                y1[pj] = y1n;
+                y2[pj] = y2n;
+            }
+        }
+        sy2[(tj + 1) * 64 + ti] = y2[PJ - 1];
+        tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gi2 = oi + ti, gj2 = oj + lj0 + pj;
+        if (gi2 >= ci0 && gi2 < ci1 && gj2 >= cj0 && gj2 < cj1) {
+            const size_t idx = base + gi2 + (size_t)M * gj2;
+            __hip_atomic_store(&Axout[idx], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <typename T, int PJ, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) void pdhg_wave_kernel(PdhgArgs A) {
     constexpr int RI = 32, RJ = 2 * PJ;

@@ -43,7 +43,7 @@ def test_every_kernel_variant_and_fusion_depth_is_bit_identical(gpu_solver_cls, 
     u0 = oracle.pdhg(f, 0.08, maxiter=97)
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
-    for variant in range(1, 19):
+    for variant in range(1, 30):
         for T_ in (1, 2, 5, 8):
             for chains in (1, 2):
                 for graph in (0, 1):
