@@ -437,7 +437,21 @@ struct Plan {
 int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     int v = p.reserved[0] - 1;  // explicit variant (1-based), 0 = auto
     const int M = h->M, N = h->N;
-    if (v < 0) v = (M > 256 || N > 256) ? 12 : 0;   // large images: 48x48 regions (variant 13), see below
+    if (v < 0) {
+        // Large images: 64-lane rows (pdhg_rows_kernel, variant 19: 64x64 region, 8 px per thread; 20: 64x48 when that
+        // still fits the chip in one round of two workgroups per CU -- measured on 1 ... 16 x 1024^2, 4 x 512^2, 8 x 300^2,
+        // 2 x 2048^2, 3 x 1100x700: 1.2-1.5 x the 48x48 tile kernel); images narrower than a
+        // region keep the 48x48 tile kernel (variant 13).
+        v = 0;
+        if (M > 256 || N > 256) {
+            v = 12;
+            if (M >= 64 && N >= 64) {
+                const int ncu = h->ncu > 0 ? h->ncu : 256;
+                auto tiles = [&](int vv) { return (double)tile_count(M, kVariants[vv].RI, 8) * tile_count(N, kVariants[vv].RJ, 8) * h->cur_nimg; };
+                v = (tiles(18) <= 2.0 * ncu && tiles(19) <= 2.0 * ncu) ? 19 : 18;
+            }
+        }
+    }
     if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
     int T = p.tile_iters;
     const bool auto_variant = p.reserved[0] <= 0;
@@ -477,7 +491,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
         // Large images (round-1 sweep over 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
         // of 3 px/thread beat the 64x64 / 4 px variant by 7-18 %; depth 8, or 6 once the grid is
         // many times the chip (the smaller halo then saves more arithmetic than the extra launches cost).
-        T = 8;
+        T = 8;   // the rows kernels: one halo wave at each end of the region
         if (v == 12 && (double)tile_count(M, V.RI, 8) * tile_count(N, V.RJ, 8) * h->cur_nimg > 8192.0) T = 6;
     }
     // the halo must leave a core when the image is larger than the region

@@ -19,7 +19,7 @@ def test_f32_matches_oracle_f32_bitwise(gpu_solver_cls, oracle, amode):
              "map": 0.02 + 0.18 * rng.random((N, M))}[amode]
     s = gpu_solver_cls(M, N, O, dtype=32)
     s.set_data(ub, f)
-    for variant in (0, 2, 13):   # the automatic plan, a 4-pixel-per-thread tile, the wide-image tile
+    for variant in (0, 2, 13, 19, 24):   # the automatic plan, a 4-pixel-per-thread tile, the wide-image tile, 64-lane rows
         u = s.denoise(alpha, maxiter=200, variant=variant)
         ref = oracle.pdhg_f32(f, alpha, maxiter=200)
         assert np.array_equal(u, ref), (amode, variant, np.abs(u - ref).max())

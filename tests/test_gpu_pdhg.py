@@ -157,9 +157,12 @@ def test_full_size_properties_1024(gpu_solver_cls):
     assert s.stats()["bytes_per_px_iter"] == 64.0
     u_b = s.denoise(amap, maxiter=64, variant=1, tile_iters=4)
     u_c = s.denoise(amap, maxiter=64, variant=6, tile_iters=3, use_graph=0)
-    u_d = s.denoise(amap, maxiter=64)                      # automatic plan: 48x48 regions (variant 13)
+    u_d = s.denoise(amap, maxiter=64)                      # automatic plan: 64-lane rows, 64x64 regions (variant 19)
+    st = s.stats()
+    assert (st["region_i"], st["region_j"], st["tile_iters"], st["tiles"]) == (64, 64, 8, 8 * 21 * 21)
+    u_e = s.denoise(amap, maxiter=64, variant=13)          # the 48x48 tile kernel
     assert s.stats()["tiles"] == 8 * 32 * 32
-    assert np.array_equal(u_a, u_b) and np.array_equal(u_a, u_c) and np.array_equal(u_a, u_d)
+    assert np.array_equal(u_a, u_b) and np.array_equal(u_a, u_c) and np.array_equal(u_a, u_d) and np.array_equal(u_a, u_e)
     s.denoise(amap, maxiter=256, fetch=False)
     g256 = s.duality_gap()
     assert np.all(g64 >= 0) and np.all(g256 >= 0) and np.all(g256 < g64)
@@ -170,7 +173,7 @@ def test_full_size_properties_1024(gpu_solver_cls):
 def test_full_size_matches_oracle_1024(gpu_solver_cls, oracle):
     """BASELINE config 5 at full image size against the C oracle: 2 x 1024 x 1024, the spatially varying alpha
     of SURVEY 8(d), 32 iterations (the oracle does this in well under a second on the host).  Bit-exact for
-    the automatic plan (48x48 regions, variant 13) and for the 64x64 / 4 px variant."""
+    the automatic plan (64-lane rows, 64x64 regions, variant 19), the 48x48 tile kernel and the 64x64 / 4 px variant."""
     O, N, M = 2, 1024, 1024
     ub, f = synth_batch(O, N, M, seed=10)
     jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
@@ -180,10 +183,38 @@ def test_full_size_matches_oracle_1024(gpu_solver_cls, oracle):
     s.set_data(ub, f)
     u_auto = s.denoise(amap, maxiter=32)
     st = s.stats()
-    assert st["tiles"] == O * 32 * 32 and st["bytes_per_px_iter"] == 64.0     # 48x48 regions, T = 8
+    assert st["tiles"] == O * 21 * 21 and st["region_i"] == 64 and st["bytes_per_px_iter"] == 64.0     # 64x64 regions, T = 8
     assert np.array_equal(u_auto, u0)
     assert np.array_equal(s.denoise(amap, maxiter=32, variant=2), u0)
+    assert np.array_equal(s.denoise(amap, maxiter=32, variant=13), u0)
     assert np.array_equal(s.denoise(0.1, maxiter=32), oracle.pdhg(f, 0.1, maxiter=32, nthreads=8))   # scalar alpha
+    s.close()
+
+
+@pytest.mark.parametrize("amode", ["scalar", "patch", "map"])
+def test_rows_kernel_alpha_modes_and_huber(gpu_solver_cls, oracle, amode):
+    """pdhg_rows_kernel (64-lane rows, i-neighbours by lane shifts, j-strips in registers, halo rows that stop early) on a
+    shape that is no multiple of anything, every parameter form, with and without the Huber term, several fusion depths
+    and region heights, f and alpha in registers or in LDS: bit-exact against the oracle.  Images narrower than a region
+    are refused for these variants (the automatic plan then keeps the tile kernel)."""
+    O, N, M = 2, 131, 203
+    ub, f = synth_batch(O, N, M, seed=31)
+    alpha = {"scalar": 0.09, "patch": np.array([[0.05, 0.12, 0.07], [0.2, 0.08, 0.1]]),
+             "map": 0.03 + 0.15 * np.random.default_rng(6).random((N, M))}[amode]
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    for rho in (0.0, 0.3):
+        u0 = oracle.pdhg(f, alpha, maxiter=53, rho=rho, nthreads=4)
+        for variant, T_ in ((19, 8), (19, 3), (20, 8), (21, 8), (21, 11), (24, 8), (24, 5), (29, 8)):
+            u = s.denoise(alpha, maxiter=53, rho=rho, variant=variant, tile_iters=T_)
+            assert np.array_equal(u, u0), (amode, rho, variant, T_)
+    s.close()
+    s = gpu_solver_cls(60, 300, 1)
+    s.set_data(*synth_batch(1, 300, 60, seed=2))
+    with pytest.raises(RuntimeError, match="at least 64x64"):
+        s.denoise(0.1, maxiter=8, variant=19)
+    u = s.denoise(0.1, maxiter=8)                          # automatic plan: the 48x48 tile kernel
+    assert s.stats()["region_i"] == 48
     s.close()
 
 
