@@ -196,8 +196,28 @@ def binding_bound(launch_us, valu, hbm_frac_measured, redundancy):
             "candidates": {k: v for k, v in cands}}
 
 
+def tile_count_py(L, R, T):
+    """tile_count of csrc/pdhg_kernels.hpp: regions of R pixels with halo T covering L pixels (image borders need no halo)."""
+    if L <= R:
+        return 1
+    S = R - 2 * T
+    a = 0
+    while True:
+        cs = 0 if a == 0 else (R - T) + (a - 1) * S
+        oo = 0 if a == 0 else cs - T
+        if oo + R >= L:
+            return a + 1
+        a += 1
+
+
+def kernel_name(st):
+    """The PDHG kernel a solve ran (stats.pdhg_variant indexes the variant table of csrc/bpltv.hip)."""
+    v = st.get("pdhg_variant", 0)
+    return "pdhg_rows_kernel" if v >= 19 else ("pdhg_wave_kernel" if v >= 16 else "pdhg_tile_kernel")
+
+
 def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
-    """The `roofline` object for pdhg_tile_kernel from one solve's statistics."""
+    """The `roofline` object for the PDHG kernel (pdhg_tile_kernel; pdhg_rows_kernel on large images) from one solve's statistics."""
     bytes_px = st["bytes_per_px_iter"]
     bytes_per_launch = bytes_px * M * N * O_local * (iters / max(st["launches"], 1))
     achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
@@ -221,6 +241,14 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
     # occupies a SIMD for 4 cycles) / (CUs * 4 SIMDs) / 2.4 GHz.
     nit_avg = iters / max(st["launches"], 1)
     computed_px_it = st["tiles"] * st["region_i"] * st["region_j"] * nit_avg
+    if kernel_name(st) == "pdhg_rows_kernel":
+        # halo pixel rows stop once nobody reads them (pdhg_rows_kernel): row k next to a near region edge that is not
+        # the image border runs k of the T iterations, row k next to such a far edge k + 1 -- T(T+1)/2 resp. T(T-1)/2
+        # row-iterations saved per region (of 64 lanes) and edge
+        T_, RJ = st["tile_iters"], st["region_j"]
+        nTj = tile_count_py(N, RJ, T_)
+        saved_rows = (nTj - 1) * (T_ * (T_ + 1) / 2 + T_ * (T_ - 1) / 2) / nTj     # per region, in row-iterations at depth T
+        computed_px_it -= st["tiles"] * st["region_i"] * saved_rows * (nit_avg / T_)
     useful_px_it = M * N * O_local * nit_avg
     redundancy = computed_px_it / useful_px_it
     valu = None
@@ -236,7 +264,7 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
     measured_hbm_frac = (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None
     return {"bound": "hbm", "bound_note": "contractual: algorithmic bytes (SURVEY 8d: 56/64 B per pixel-iteration) / launch time; "
                                           "the fused kernel touches HBM once per tile_iters iterations, see `binding`",
-            "kernel": "pdhg_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "kernel": kernel_name(st), "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "measured_hbm_frac": measured_hbm_frac,   # counter traffic / launch time / peak: the HBM share actually used
             "binding": binding_bound(launch_us, valu, measured_hbm_frac, redundancy),

@@ -46,7 +46,7 @@ class BpltvStats(C.Structure):
         ("shards", C.c_int), ("collective", C.c_int),
         ("collective_ms", C.c_double),
         ("nccl_ranks", C.c_int), ("hb_sync", C.c_int), ("adjoint_chunks", C.c_int),
-        ("reserved", C.c_int * 1),
+        ("pdhg_variant", C.c_int),
     ]
 
     def as_dict(self):

@@ -673,6 +673,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     }
     if (rc) return rc;
     h->st.tile_iters = pl.T;
+    h->st.pdhg_variant = pl.variant + 1;
     h->st.tiles = pl.grid;
     h->st.region_i = kVariants[pl.variant].RI;
     h->st.region_j = kVariants[pl.variant].RJ;
@@ -1386,7 +1387,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     const int nTi = tile_count(M, SR_R, 2 * T), nTj = tile_count(N, SR_R, 2 * T);
     if (nTi < 1 || nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
     const int grid = nTi * nTj * h->O;
-    h->st.tile_iters = T; h->st.tiles = grid; h->st.region_i = SR_R; h->st.region_j = SR_R;
+    h->st.tile_iters = T; h->st.tiles = grid; h->st.region_i = SR_R; h->st.region_j = SR_R; h->st.pdhg_variant = vi + 1;
     h->st.launches = 0; h->st.iterations = p.maxiter; h->st.graph_used = 0; h->st.last_gap = -1.0;
     if (p.maxiter == 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_sr[0][0], h->d_f, h->tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));

@@ -142,7 +142,9 @@ typedef struct bpltv_stats {
                                   0 not used, 1 HIP events, 2 stream memory operations (hipStreamWaitValue32)    */
     int adjoint_chunks;        /* image groups the last adjoint gradient was processed in (1 = whole batch at once;
                                   more when the factor workspace of all images does not fit, BPLTV_ADJ_BUDGET_MB) */
-    int reserved[1];
+    int pdhg_variant;          /* 1-based index of the PDHG kernel the last solve ran (the variant table of
+                                  csrc/bpltv.hip: 1..15 pdhg_tile_kernel, 16..18 pdhg_wave_kernel, 19.. pdhg_rows_kernel;
+                                  sum of regularisers: 1 sr_tile_kernel, 2 sr_strip_kernel)                      */
 } bpltv_stats_t;
 
 #define BPLTV_RESIDUAL_GATE 1e-6

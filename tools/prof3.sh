@@ -5,14 +5,14 @@
 # combined with --pmc.  New this round: the nested-dissection adjoint (tools/_bin/nd_unit and the two evaluate
 # probes) and one counter pass over the HBM band solver's unit binary with event-based stream dependencies
 # (VERDICT r2 item 4 / ADVICE: its log is kept whatever the outcome).
-# usage: tools/prof3.sh [part ...]   parts: bench eval128 evalcfg5 nd hb sumregs   (default: all)
+# usage: tools/prof3.sh [part ...]   parts: bench cfg5 eval128 evalcfg5 nd hb sumregs   (default: all)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof3
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
-PARTS=${@:-bench eval128 evalcfg5 nd hb sumregs}
+PARTS=${@:-bench cfg5 eval128 evalcfg5 nd hb sumregs}
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
 SQ2="SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
 kt()  { local tag=$1; shift; echo "== kernel trace $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- "$@" > $OUT/$tag.log 2>&1 || { tail -5 $OUT/$tag.log; exit 1; }; python3 tools/refresh_profiles.py aggregate $OUT/$tag; }
@@ -23,6 +23,17 @@ bench)
   python3 bench.py --steps 10 --warmup 3 > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
   tail -1 $OUT/bench.log | cut -c1-300
   kt kt_bench python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+  ;;
+cfg5)
+  # config 5's per-GPU share through the PDHG kernel of large images (pdhg_rows_kernel): line, trace, counters
+  C="python3 bench.py --images 8 --size 1024 --alpha-map --iters 400 --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+  $C > $OUT/bench_cfg5.log 2>&1 || { tail -20 $OUT/bench_cfg5.log; exit 1; }
+  tail -1 $OUT/bench_cfg5.log | cut -c1-400
+  kt kt_cfg5 $C
+  pmc pmc_cfg5_sq1 "$SQ1" $C --no-graph
+  pmc pmc_cfg5_sq2 "$SQ2" $C --no-graph
+  pmc pmc_cfg5_fetch "FETCH_SIZE" $C --no-graph
+  pmc pmc_cfg5_write "WRITE_SIZE" $C --no-graph
   ;;
 eval128)
   python3 tools/eval_once.py > $OUT/eval_128.log 2>&1 || { tail -20 $OUT/eval_128.log; exit 1; }

@@ -111,7 +111,7 @@ def publish(tag):
         tl = newest(os.path.join(sub, "**", "timeline_summary.csv"))
         if tl:
             shutil.copy(tl, os.path.join(PRO, "%s_%s_timeline.csv" % (tag, name.replace("kernel_stats_", "")))); copied.append(name + "_timeline")
-    for sub, name in (("pmc_bench_sq1", "pmc_sq_pdhg"), ("pmc_cfg5_sq1", "pmc_sq_cfg5_pdhg"), ("pmc_eval128_sq1", "pmc_sq1_evaluate_128"),
+    for sub, name in (("pmc_bench_sq1", "pmc_sq_pdhg"), ("pmc_cfg5_sq1", "pmc_sq_cfg5_pdhg"), ("pmc_cfg5_sq2", "pmc_sq2_cfg5_pdhg"), ("pmc_eval128_sq1", "pmc_sq1_evaluate_128"),
                       ("pmc_eval128_sq2", "pmc_sq2_evaluate_128"), ("pmc_evalcfg5_sq1", "pmc_sq1_cfg5_evaluate"),
                       ("pmc_evalcfg5_sq2", "pmc_sq2_cfg5_evaluate"), ("pmc_evalcfg5_fetch", "pmc_fetch_cfg5_evaluate"),
                       ("pmc_evalcfg5_write", "pmc_write_cfg5_evaluate"), ("pmc_bench_fetch", "pmc_fetch_pdhg"),
@@ -146,9 +146,9 @@ def publish(tag):
     tj["correction"] = ("gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, section HBM); "
                         "WRITE_SIZE exact; both in KiB per dispatch")
     for key, pre, line in (("10x128x128 scalar", "pmc_bench", "bench_line"), ("8x1024x1024 map", "pmc_cfg5", "bench_line_cfg5")):
-        fe = pmc_mean(pre + "_fetch", "pdhg_tile_kernel", "FETCH_SIZE")
-        wr = pmc_mean(pre + "_write", "pdhg_tile_kernel", "WRITE_SIZE")
-        vi = pmc_mean(pre + "_sq1", "pdhg_tile_kernel", "SQ_INSTS_VALU")
+        fe = pmc_mean(pre + "_fetch", "pdhg_", "FETCH_SIZE")      # pdhg_tile_kernel or pdhg_rows_kernel: the one with most dispatches
+        wr = pmc_mean(pre + "_write", "pdhg_", "WRITE_SIZE")
+        vi = pmc_mean(pre + "_sq1", "pdhg_", "SQ_INSTS_VALU")
         bl = os.path.join(PRO, "%s_%s.json" % (tag, line))
         if fe is None or wr is None or not os.path.exists(bl):
             continue
@@ -159,7 +159,7 @@ def publish(tag):
             "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
             "valu_wave_instructions_per_launch": vi,
             "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
-            "source": "tools/prof2.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
+            "source": "tools/prof2.sh / prof3.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
         }
     json.dump(tj, open(tf, "w"), indent=1)
     print("published:", ", ".join(copied))
