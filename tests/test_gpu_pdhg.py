@@ -263,6 +263,29 @@ def test_run_time_choices_of_the_unpinned_recurrence_are_bit_exact(gpu_solver_cl
     s.close()
 
 
+def test_run_time_choices_and_gap_checks_on_a_large_image(gpu_solver_cls, oracle):
+    """The same switches, the chunked launch sequence with duality-gap checks and a parameter sweep on an image above
+    256 px, where the automatic plan is pdhg_rows_kernel (starts from a prepared state, several problems per image)."""
+    O, N, M = 2, 290, 270
+    ub, f = synth_batch(O, N, M, seed=12)
+    alpha = 0.05 + 0.1 * np.random.default_rng(4).random((N, M))
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    for init, order in ((1, 0), (0, 1), (1, 1)):
+        for maxiter in (1, 9, 70):
+            u = s.denoise(alpha, maxiter=maxiter, init=init, order=order)
+            assert s.stats()["region_i"] == 64 and s.stats()["pdhg_variant"] in (19, 20)
+            assert np.array_equal(u, oracle.pdhg_opts(f, alpha, maxiter=maxiter, init=init, order=order)), (init, order, maxiter)
+    u = s.denoise(alpha, maxiter=70, check_every=24)
+    assert np.array_equal(u, oracle.pdhg(f, alpha, maxiter=70, nthreads=4))
+    alphas = [0.03, 0.08, 0.2]
+    costs, us = s.sweep(alphas, fetch_u=True, maxiter=40)
+    for k, a in enumerate(alphas):
+        u0 = oracle.pdhg(f, a, maxiter=40, nthreads=4)
+        assert np.array_equal(us[k], u0) and np.isclose(costs[k], oracle.cost(u0, ub), rtol=1e-12), a
+    s.close()
+
+
 def test_run_time_choices_are_rejected_where_unsupported(gpu_solver_cls):
     from bpldenoising_amd._lib import BpltvError
     ub, f = synth_batch(1, 32, 32, seed=2)
