@@ -445,7 +445,9 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
         v = 0;
         if (M > 256 || N > 256) {
             v = 12;
-            if (M >= 64 && N >= 64) {
+            // (dtype 32 keeps the tile kernel: the float instantiation of the rows kernel is packed into v_pk_* pairs
+            //  by the SLP vectoriser at the price of 300 register moves per iteration -- 2.3e4 against 3.6e4 it/s)
+            if (M >= 64 && N >= 64 && h->dtype != 32) {
                 const int ncu = h->ncu > 0 ? h->ncu : 256;
                 auto tiles = [&](int vv) { return (double)tile_count(M, kVariants[vv].RI, 8) * tile_count(N, kVariants[vv].RJ, 8) * h->cur_nimg; };
                 v = (tiles(18) <= 2.0 * ncu && tiles(19) <= 2.0 * ncu) ? 19 : 18;
