@@ -465,19 +465,26 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
         // fewer launches but smaller cores, i.e. more (redundant) tiles; the larger region wastes fewer pixels on
         // halos and wins once the batch no longer fits the chip with 32x32 regions (16 images of 128^2: -10 %,
         // 32: -27 %).  Results do not depend on the choice.
-        struct Cand { int v; double one, two; };
-        const Cand cands[2] = {{0, 0.47, 0.94}, {12, 1.36, 2.1}};
+        // Round 3: the rows kernels (64x64 / 8 px: 1.95 us alone on a CU, 3.5 us per round of two; 64x48 / 6 px: 1.6 /
+        // 2.7 us; depth 8 only: their halo is one wave) join for images of at least one region -- they take over from
+        // about 16 images of 256^2 or 10 of 200^2 (+15-23 %), not for the 10 x 128^2 batch.
+        struct Cand { int v; double one, two; int tmin, tmax; };
+        const Cand cands[4] = {{0, 0.47, 0.94, 2, 12}, {12, 1.36, 2.1, 2, 12}, {18, 1.95, 3.5, 8, 8}, {19, 1.6, 2.7, 8, 8}};
         double best = 1e300;
         const int ncu = h->ncu > 0 ? h->ncu : 256;
         for (const Cand& cd : cands) {
             if (cd.v != 0 && !auto_variant) continue;
             const Variant& Vc = kVariants[cd.v];
-            for (int t = 2; t <= 12; ++t) {
+            if (Vc.min_image && (M < Vc.RI || N < Vc.RJ || h->dtype == 32)) continue;
+            for (int t = cd.tmin; t <= cd.tmax; ++t) {
                 if ((M > Vc.RI && 2 * t >= Vc.RI) || (N > Vc.RJ && 2 * t >= Vc.RJ)) continue;   // no core left
                 const int a = tile_count(M, Vc.RI, t), b = tile_count(N, Vc.RJ, t);
                 if (a < 1 || b < 1) continue;
                 const double tiles = (double)a * b * h->cur_nimg;
-                const double per_iter = (tiles <= ncu) ? cd.one : cd.two * std::ceil(tiles / (2.0 * ncu));
+                const double rounds = tiles / (2.0 * ncu);
+                // whole rounds for the short tile workgroups; the long rows workgroups overlap the tail of a round
+                const double eff = Vc.min_image ? (rounds <= 1.0 ? 1.0 : 0.5 * (std::ceil(rounds) + rounds)) : std::ceil(rounds);
+                const double per_iter = (tiles <= ncu) ? cd.one : cd.two * eff;
                 const double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
                 if (cost < best) { best = cost; T = t; v = cd.v; }
             }
