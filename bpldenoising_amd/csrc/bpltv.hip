@@ -445,9 +445,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
         v = 0;
         if (M > 256 || N > 256) {
             v = 12;
-            // (dtype 32 keeps the tile kernel: the float instantiation of the rows kernel is packed into v_pk_* pairs
-            //  by the SLP vectoriser at the price of 300 register moves per iteration -- 2.3e4 against 3.6e4 it/s)
-            if (M >= 64 && N >= 64 && h->dtype != 32) {
+            if (M >= 64 && N >= 64) {
                 const int ncu = h->ncu > 0 ? h->ncu : 256;
                 auto tiles = [&](int vv) { return (double)tile_count(M, kVariants[vv].RI, 8) * tile_count(N, kVariants[vv].RJ, 8) * h->cur_nimg; };
                 v = (tiles(18) <= 2.0 * ncu && tiles(19) <= 2.0 * ncu) ? 19 : 18;
@@ -475,7 +473,7 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
         for (const Cand& cd : cands) {
             if (cd.v != 0 && !auto_variant) continue;
             const Variant& Vc = kVariants[cd.v];
-            if (Vc.min_image && (M < Vc.RI || N < Vc.RJ || h->dtype == 32)) continue;
+            if (Vc.min_image && (M < Vc.RI || N < Vc.RJ)) continue;
             for (int t = cd.tmin; t <= cd.tmax; ++t) {
                 if ((M > Vc.RI && 2 * t >= Vc.RI) || (N > Vc.RJ && 2 * t >= Vc.RJ)) continue;   // no core left
                 const int a = tile_count(M, Vc.RI, t), b = tile_count(N, Vc.RJ, t);
