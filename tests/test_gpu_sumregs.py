@@ -142,6 +142,36 @@ def test_drivers_hip_vs_oracle(gpu_solver_cls, oracle, tmp_path):
     B.learning_function.clear_cache()
 
 
+def test_gradients_in_image_groups_are_bitwise_the_whole_batch(gpu_solver_cls, monkeypatch):
+    """The sum-of-regularisers gradients under a forced workspace budget (BPLTV_ADJ_BUDGET_MB): nested-dissection Cholesky
+    and its LU variant (patch parameter, Delta <= Delta_t) run in image groups and return bitwise the whole-batch result."""
+    import os, re, subprocess
+    from conftest import ROOT
+    O, N, M = 5, 64, 80
+    ub, f = synth_batch(O, N, M, seed=44)
+    out = subprocess.run([os.path.join(ROOT, "tools", "_bin", "nd_host_check"), "bytes", str(M), str(N)], capture_output=True, text=True, timeout=120).stdout
+    per_image = float(re.search(r"bytes_per_image sr (\d+)", out).group(1))
+    res = {}
+    for budget in (None, 2.5 * per_image / 1e6):
+        if budget is None:
+            monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB", raising=False)
+        else:
+            monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "%.4f" % budget)
+        s = gpu_solver_cls(M, N, O)
+        s.set_data(ub, f)
+        _, c, g = s.sumregs_evaluate(P3, 0.1, maxiter=300)
+        ch = s.stats()["adjoint_chunks"]
+        _, cr, gr = s.sumregs_evaluate(P3, 1e-4, maxiter=300)
+        st = s.stats()
+        assert st["adjoint_method"] == "nd-lu" and st["reg_gradient_used"] == 1
+        res[budget is None] = (c, np.asarray(g), cr, np.asarray(gr), ch, st["adjoint_chunks"])
+        s.close()
+    whole, grouped = res[True], res[False]
+    assert whole[4] == 1 and whole[5] == 1 and grouped[4] == 3 and grouped[5] >= 3      # 2 images per group; the LU workspace is twice as large
+    assert whole[0] == grouped[0] and np.array_equal(whole[1], grouped[1])
+    assert whole[2] == grouped[2] and np.array_equal(whole[3], grouped[3])
+
+
 def test_sharded_handle(gpu_solver_cls):
     ub, f = synth_batch(4, 40, 36, seed=22)
     s1 = gpu_solver_cls(36, 40, 4)
