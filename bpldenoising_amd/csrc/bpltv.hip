@@ -20,6 +20,7 @@
 #include "adjoint_hbm_kernels.hpp"
 #include "hb_band_solver.hpp"
 #include "hb_lu_solver.hpp"
+#include <thread>
 #include "nd_solver.hpp"
 #include "adjoint_bcr_kernels.hpp"
 #include "adjoint_kernels.hpp"
@@ -516,7 +517,15 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
     // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
     int ch = p.reserved[1];
-    if (ch <= 0) ch = 1;  // with write-through state stores one chain is as fast as two and steadier (round-1 A/B)
+    if (ch <= 0) {
+        // Two chains once the batch no longer fits the chip with one workgroup per CU: the second chain's kernels run in
+        // the first one's launch gaps (10 x 128^2: 7.2e5 -> 8.5e5 it/s; 8 / 32 / 64 images +18 / 26 / 16 %; the large-image
+        // workloads +2 %).  Smaller batches are faster as one chain (2-5 images: -3 ... -10 % with two).  Chain 0 runs on
+        // the handle's own stream, chain 1 on a second one: those two hardware queues overlap; a third does not (it shares
+        // a pipe with the second: 3 chains 7.8e5) -- DESIGN.md section 4.1.
+        const int ncu = h->ncu > 0 ? h->ncu : 256;
+        ch = (pl->grid > ncu && h->cur_nimg >= 2) ? 2 : 1;
+    }
     if (ch > h->cur_nimg) ch = h->cur_nimg;
     pl->chains = ch;
     return BPLTV_OK;
@@ -536,7 +545,14 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         HIPCHK(h, hipGraphCreate(&g, 0));
         hipGraphNode_t prev = nullptr;
         int cur = from_state ? 1 : 0;   // a prepared start lives in set 1; launch 0 always writes set 0
-        for (int it = 0; it < niter; it += pl.T) {
+        // Odd chains run half a launch out of phase: their first launch fuses T/2 iterations only, so that one chain's
+        // launch gaps fall into the other chain's arithmetic instead of both idling and both computing together (chains
+        // of equal size otherwise stay in lockstep).  Such a chain has one launch more; it starts by writing set 1, so
+        // that every chain ends in the same set.  Results do not depend on how the iterations are cut into launches.
+        const int nl0 = (niter + pl.T - 1) / pl.T, h0 = pl.T / 2;
+        const bool stagger = (c & 1) && !from_state && pl.T >= 2 && nl0 >= 8 && ((1 + (niter - h0 + pl.T - 1) / pl.T) - nl0) % 2 == 1;
+        int step = stagger ? h0 : pl.T;
+        for (int it = 0; it < niter; it += step, step = pl.T) {
             PdhgArgs a;
             a.f = pdhg_f(h); a.alpha = pdhg_alpha(h); a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
@@ -547,12 +563,12 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
 #ifdef BPLTV_EXPERIMENTS
             a.dbg = p.reserved[3];
 #endif
-            const int nxt = (it == 0) ? 0 : 1 - cur;
+            const int nxt = (it == 0) ? (stagger ? 1 : 0) : 1 - cur;
             a.first = (it == 0 && !from_state) ? 1 : 0;
             a.xin = pdhg_state(h, cur, 0); a.y1in = pdhg_state(h, cur, 1); a.y2in = pdhg_state(h, cur, 2);
             a.xout = pdhg_state(h, nxt, 0); a.y1out = pdhg_state(h, nxt, 1); a.y2out = pdhg_state(h, nxt, 2);
             a.it0 = it;
-            a.nit = std::min(pl.T, niter - it);
+            a.nit = std::min(step, niter - it);
             void* kargs[] = {&a};
             hipKernelNodeParams kp;
             std::memset(&kp, 0, sizeof(kp));
@@ -741,7 +757,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                     // together) -- used by bench.py to time an isolated launch, as rocprofv3 sees it
                     for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, hipGraphLaunch(ex[c], h->stream));
                 } else {
-                    while (h->chain_streams.size() < ex.size()) {
+                    while (h->chain_streams.size() + 1 < ex.size()) {   // chain 0 runs on the handle's own stream
                         hipStream_t cs = nullptr;
                         hipEvent_t ce = nullptr;
                         HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -749,13 +765,31 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                         h->chain_streams.push_back(cs);
                         h->chain_events.push_back(ce);
                     }
-                    for (size_t c = 0; c < ex.size(); ++c) {  // fork: every chain waits for ev[0]
-                        HIPCHK(h, hipStreamWaitEvent(h->chain_streams[c], h->ev[0], 0));
-                        HIPCHK(h, hipGraphLaunch(ex[c], h->chain_streams[c]));
-                        HIPCHK(h, hipEventRecord(h->chain_events[c], h->chain_streams[c]));
+                    // fork: every chain waits for ev[0].  hipGraphLaunch walks the graph on the calling thread (a few
+                    // us of host time per kernel node), so the chains are launched from one host thread each --
+                    // launched one after the other from this thread the second chain starts when the first is
+                    // half done and nothing overlaps (measured: 6.83e5 it/s against 8.2e5 on the 10 x 128^2 batch).
+                    std::vector<hipError_t> cerr(ex.size(), hipSuccess);
+                    auto launch_chain = [&](size_t c) {
+                        hipError_t e = hipSetDevice(h->device);
+                        if (c == 0) {
+                            if (e == hipSuccess) e = hipGraphLaunch(ex[0], h->stream);
+                        } else {
+                            if (e == hipSuccess) e = hipStreamWaitEvent(h->chain_streams[c - 1], h->ev[0], 0);
+                            if (e == hipSuccess) e = hipGraphLaunch(ex[c], h->chain_streams[c - 1]);
+                            if (e == hipSuccess) e = hipEventRecord(h->chain_events[c - 1], h->chain_streams[c - 1]);
+                        }
+                        cerr[c] = e;
+                    };
+                    {
+                        std::vector<std::thread> th;
+                        for (size_t c = 1; c < ex.size(); ++c) th.emplace_back(launch_chain, c);
+                        launch_chain(0);
+                        for (auto& t : th) t.join();
                     }
-                    for (size_t c = 0; c < ex.size(); ++c)  // join
-                        HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[c], 0));
+                    for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, cerr[c]);
+                    for (size_t c = 1; c < ex.size(); ++c)  // join
+                        HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[c - 1], 0));
                 }
                 buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
                 launches = nl * (int)ex.size();
