@@ -226,21 +226,28 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
     # and are labelled with their source.
     wl_key = "%dx%dx%d %s" % (O_local, N, M, "map" if bytes_px in (64.0, 32.0) else "scalar")
     traffic, traffic_src, valu_instr = None, None, None
+    # the library runs the batch as `chains` concurrent launch chains (image groups) of tiles / chains workgroups per
+    # dispatch; the counter passes run eager single-chain launches of the whole grid: counters scale with the workgroups
+    nl = -(-iters // max(st["tile_iters"], 1))
+    chains = max(1, round(st["launches"] / max(nl, 1)))
+    tiles_disp = st["tiles"] / chains
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and not f32:   # the committed counters are those of the Float64 kernel
         try:
             tj = json.load(open(tf)).get("workloads", {}).get(wl_key)
-            if tj and tj.get("tile_iters") == st["tile_iters"] and tj.get("tiles") == st["tiles"]:
-                traffic = tj.get("hbm_bytes_per_launch")
-                valu_instr = tj.get("valu_wave_instructions_per_launch")
-                traffic_src = "profiles/traffic.json[%s] (%s)" % (wl_key, tj.get("round", "?"))
+            if tj and tj.get("tile_iters") == st["tile_iters"] and tj.get("tiles") in (st["tiles"], round(tiles_disp)):
+                scale = tiles_disp / tj["tiles"]
+                traffic = tj.get("hbm_bytes_per_launch") * scale
+                valu_instr = tj.get("valu_wave_instructions_per_launch") * scale if tj.get("valu_wave_instructions_per_launch") else None
+                traffic_src = "profiles/traffic.json[%s] (%s%s)" % (wl_key, tj.get("round", "?"),
+                                                                    "" if scale == 1.0 else ", scaled by %.3g: %d of its %d workgroups per dispatch" % (scale, round(tiles_disp), tj["tiles"]))
         except Exception:
             traffic = None
     # the temporal blocking trades HBM traffic for redundant halo arithmetic, so beside the contractual HBM figure
     # the line carries the redundancy and the f64 VALU issue floor: wave-instructions * 4 cycles (a wave64 f64 op
     # occupies a SIMD for 4 cycles) / (CUs * 4 SIMDs) / 2.4 GHz.
-    nit_avg = iters / max(st["launches"], 1)
-    computed_px_it = st["tiles"] * st["region_i"] * st["region_j"] * nit_avg
+    nit_avg = iters * chains / max(st["launches"], 1)   # iterations per dispatch; a dispatch holds tiles / chains workgroups
+    computed_px_it = tiles_disp * st["region_i"] * st["region_j"] * nit_avg
     if kernel_name(st) == "pdhg_rows_kernel":
         # halo pixel rows stop once nobody reads them (pdhg_rows_kernel): row k next to a near region edge that is not
         # the image border runs k of the T iterations, row k next to such a far edge k + 1 -- T(T+1)/2 resp. T(T-1)/2
@@ -248,8 +255,8 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
         T_, RJ = st["tile_iters"], st["region_j"]
         nTj = tile_count_py(N, RJ, T_)
         saved_rows = (nTj - 1) * (T_ * (T_ + 1) / 2 + T_ * (T_ - 1) / 2) / nTj     # per region, in row-iterations at depth T
-        computed_px_it -= st["tiles"] * st["region_i"] * saved_rows * (nit_avg / T_)
-    useful_px_it = M * N * O_local * nit_avg
+        computed_px_it -= tiles_disp * st["region_i"] * saved_rows * (nit_avg / T_)
+    useful_px_it = M * N * O_local / chains * nit_avg
     redundancy = computed_px_it / useful_px_it
     valu = None
     if valu_instr:
@@ -273,6 +280,7 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
             "avg_kernel_us_serialized": kernel_us,
             "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
+            "launch_chains": chains,   # concurrent chains of image groups: avg_launch_us = whole time / all dispatches
             "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
             "bytes_per_px_iter": bytes_px}
 

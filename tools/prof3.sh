@@ -23,6 +23,11 @@ bench)
   python3 bench.py --steps 10 --warmup 3 > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
   tail -1 $OUT/bench.log | cut -c1-300
   kt kt_bench python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+  # counters of the headline launch as the bench runs it (two chains of 245 tiles; eager launches under the profiler)
+  B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-graph"
+  pmc pmc_bench_sq1 "$SQ1" $B
+  pmc pmc_bench_fetch "FETCH_SIZE" $B
+  pmc pmc_bench_write "WRITE_SIZE" $B
   ;;
 cfg5)
   # config 5's per-GPU share through the PDHG kernel of large images (pdhg_rows_kernel): line, trace, counters

@@ -158,7 +158,8 @@ def publish(tag):
             "FETCH_SIZE_KiB_per_launch": fe, "WRITE_SIZE_KiB_per_launch": wr,
             "hbm_bytes_per_launch": (2 * fe + wr) * 1024,
             "valu_wave_instructions_per_launch": vi,
-            "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+            # the counter passes launch the whole grid eagerly; the bench line's dispatch holds 1 / launch_chains of it
+            "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"] * b["roofline"].get("launch_chains", 1),
             "source": "tools/prof2.sh / prof3.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
         }
     json.dump(tj, open(tf, "w"), indent=1)
