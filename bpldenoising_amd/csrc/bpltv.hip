@@ -234,7 +234,7 @@ struct bpltv_handle {
     NdSolver nd_sr_lu;            // ... the same system by nested dissection (LU variant; the default)
     bool lu_sr_ready = false;
     double* d_srdiagU = nullptr;  // its upper diagonals (7 planes)
-    std::map<SrGraphKey, hipGraphExec_t> sr_graphs;
+    std::map<SrGraphKey, std::vector<hipGraphExec_t>> sr_graphs;   // one graph per launch chain
     bpltv_stats_t st;
     std::string err;
 };
@@ -1364,7 +1364,8 @@ int sr_upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
     h->alpha_min = amin;
     if (h->alpha_cap < need) {
         drop_graphs(h);
-        for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& kv : h->sr_graphs)
+            for (auto e : kv.second) (void)hipGraphExecDestroy(e);
         h->sr_graphs.clear();
         int rc = ensure(h, &h->d_alpha, &h->alpha_cap, need);
         if (rc) return rc;
@@ -1437,30 +1438,33 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
         h->sr_result_buf = 0; h->sr_has_result = true; h->last_is_sr = true; h->st.pdhg_ms = 0.0;
         return BPLTV_OK;
     }
-    // iterations [it0, it1) from the state set `cur`; returns the set holding the result
-    auto enqueue_range = [&](hipStream_t st, int it0, int it1, int cur) -> int {
-        for (int it = it0; it < it1; it += T) {
+    // iterations [it0, it1) of the images [lo, hi) from the state set `cur`; returns the set holding the result.
+    // stagger: the chain's first launch fuses T/2 iterations and writes set 1 (run_pdhg's launch chains).
+    auto enqueue_range = [&](hipStream_t st, int it0, int it1, int cur, int lo, int hi, bool stagger) -> int {
+        int step = stagger ? std::max(1, T / 2) : T;
+        for (int it = it0; it < it1; it += step, step = T) {
             SrArgs a;
-            const int nxt = (it == 0) ? 0 : 1 - cur;
+            const int nxt = (it == 0) ? (stagger ? 1 : 0) : 1 - cur;
             for (int c = 0; c < 7; ++c) { a.in[c] = h->d_sr[cur][c]; a.out[c] = h->d_sr[nxt][c]; }
             a.f = h->d_f; a.alpha = h->d_alpha; a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
-            a.it0 = it; a.nit = std::min(T, it1 - it);
+            a.it0 = it; a.nit = std::min(step, it1 - it);
             a.M = M; a.N = N; a.O = h->O; a.nTi = nTi; a.nTj = nTj; a.halo = 2 * T;
             a.first = (it == 0) ? 1 : 0;
-            hipLaunchKernelGGL(V.kernel, dim3(grid), dim3(V.threads), V.lds, st, a);
+            a.img0 = lo;
+            hipLaunchKernelGGL(V.kernel, dim3(nTi * nTj * (hi - lo)), dim3(V.threads), V.lds, st, a);
             cur = nxt;
         }
         return cur;
     };
-    auto enqueue = [&](hipStream_t st) -> int { return enqueue_range(st, 0, p.maxiter, 0); };
+    auto enqueue = [&](hipStream_t st) -> int { return enqueue_range(st, 0, p.maxiter, 0, 0, h->O, false); };
     if (p.check_every > 0) {   // duality-gap checks every check_every iterations, early stop at gap_tol (as the TV model)
         HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
         int it = 0, cur = 0, launches = 0;
         h->last_is_sr = true;
         while (it < p.maxiter) {
             const int it1 = std::min(p.maxiter, it + p.check_every);
-            cur = enqueue_range(h->stream, it, it1, cur);
+            cur = enqueue_range(h->stream, it, it1, cur, 0, h->O, false);
             launches += (it1 - it + T - 1) / T;
             it = it1;
             HIPCHK(h, hipGetLastError());
@@ -1486,31 +1490,69 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     }
     const int nl = (p.maxiter + T - 1) / T;
     const int buf = (nl - 1) % 2 == 0 ? 0 : 1;   // launch 0 writes set 0, launch l writes set l % 2
+    // two launch chains (image groups) as in run_pdhg: chain 0 on the handle's stream, chain 1 on a second one, half a
+    // launch out of phase; reserved[1] = 1 keeps one chain
+    const int h0 = std::max(1, T / 2);
+    int nch = p.reserved[1] > 0 ? std::min(p.reserved[1], 2) : ((grid > (h->ncu > 0 ? h->ncu : 256) && h->O >= 2) ? 2 : 1);
+    if (nch > h->O) nch = h->O;
+    const bool stag = T >= 2 && nl >= 8 && ((1 + (p.maxiter - h0 + T - 1) / T) - nl) % 2 == 1;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     bool done = false;
     if (p.use_graph && nl <= 50000) {
-        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, vi, p.rho, p.tau0, p.sigma0, (const void*)d_tab};
+        SrGraphKey key{p.maxiter, T, h->last_am, h->last_an, p.accel ? 1 : 0, vi + 16 * nch, p.rho, p.tau0, p.sigma0, (const void*)d_tab};
         auto it = h->sr_graphs.find(key);
         if (it == h->sr_graphs.end()) {
             if (h->sr_graphs.size() >= 8) {
-                for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+                for (auto& kv : h->sr_graphs)
+                    for (auto e : kv.second) (void)hipGraphExecDestroy(e);
                 h->sr_graphs.clear();
             }
-            hipGraph_t g = nullptr;
-            hipGraphExec_t ex = nullptr;
-            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                (void)enqueue(h->stream);
-                if (hipStreamEndCapture(h->stream, &g) == hipSuccess && g &&
-                    hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-                    h->sr_graphs[key] = ex;
-                    it = h->sr_graphs.find(key);
+            std::vector<hipGraphExec_t> exs;
+            for (int c = 0; c < nch; ++c) {
+                const int lo = (int)(((long)h->O * c) / nch), hi = (int)(((long)h->O * (c + 1)) / nch);
+                hipGraph_t g = nullptr;
+                hipGraphExec_t ex = nullptr;
+                if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    (void)enqueue_range(h->stream, 0, p.maxiter, 0, lo, hi, (c & 1) && stag);
+                    if (hipStreamEndCapture(h->stream, &g) == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)
+                        exs.push_back(ex);
+                    if (g) (void)hipGraphDestroy(g);
                 }
-                if (g) (void)hipGraphDestroy(g);
             }
             (void)hipGetLastError();
+            if ((int)exs.size() == nch) {
+                h->sr_graphs[key] = exs;
+                it = h->sr_graphs.find(key);
+            } else {
+                for (auto e : exs) (void)hipGraphExecDestroy(e);
+            }
         }
         if (it != h->sr_graphs.end()) {
-            HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+            const std::vector<hipGraphExec_t>& exs = it->second;
+            if (exs.size() == 1) {
+                HIPCHK(h, hipGraphLaunch(exs[0], h->stream));
+            } else {
+                if (h->chain_streams.empty()) {
+                    hipStream_t cs = nullptr;
+                    hipEvent_t ce = nullptr;
+                    HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+                    h->chain_streams.push_back(cs);
+                    h->chain_events.push_back(ce);
+                }
+                hipError_t e1 = hipSuccess;
+                std::thread th([&]() {
+                    e1 = hipSetDevice(h->device);
+                    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(h->chain_streams[0], h->ev[0], 0);
+                    if (e1 == hipSuccess) e1 = hipGraphLaunch(exs[1], h->chain_streams[0]);
+                    if (e1 == hipSuccess) e1 = hipEventRecord(h->chain_events[0], h->chain_streams[0]);
+                });
+                const hipError_t e0 = hipGraphLaunch(exs[0], h->stream);
+                th.join();
+                HIPCHK(h, e0);
+                HIPCHK(h, e1);
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[0], 0));
+            }
             h->st.graph_used = 1;
             done = true;
         }
@@ -1522,7 +1564,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
     h->st.pdhg_ms = ms;
-    h->st.launches = nl;
+    h->st.launches = done ? nl * nch + ((nch > 1 && stag) ? 1 : 0) : nl;
     h->sr_result_buf = buf;
     h->sr_has_result = true;
     h->last_is_sr = true;
@@ -2203,7 +2245,8 @@ int bpltv_destroy(bpltv_t* h) {
     h->hb_sr.release();
     h->lu_sr.release();
     if (h->d_srdiagU) (void)hipFree(h->d_srdiagU);
-    for (auto& kv : h->sr_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->sr_graphs)
+        for (auto e : kv.second) (void)hipGraphExecDestroy(e);
     for (void* q : {(void*)h->d_srcoef, (void*)h->d_srdiag, (void*)h->d_srw, (void*)h->d_srgpix})
         if (q) (void)hipFree(q);
     for (int s2 = 0; s2 < 2; ++s2)

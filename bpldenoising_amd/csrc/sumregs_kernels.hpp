@@ -33,6 +33,7 @@ struct SrArgs {
     int M, N, O;
     int nTi, nTj, halo;    // halo = 2 * fused iterations
     int first;
+    int img0;              // first image of this launch (launch chains: grid = tiles per image * images of the chain)
 };
 
 __device__ __forceinline__ size_t sr_alpha_index(int am, int an, int M, int N, int i, int j) {
@@ -50,8 +51,9 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
     const int tid = threadIdx.x;
     const int li = tid % TI, lj = tid / TI;
     const int tilesPerImg = A.nTi * A.nTj;
-    const int img = blockIdx.x / tilesPerImg;
-    const int t = blockIdx.x - img * tilesPerImg;
+    const int imgl = blockIdx.x / tilesPerImg;
+    const int img = A.img0 + imgl;
+    const int t = blockIdx.x - imgl * tilesPerImg;
     const int ta = t % A.nTi, tb = t / A.nTi;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
@@ -187,8 +189,9 @@ __global__ __launch_bounds__(TI* TJ) void sr_strip_kernel(SrArgs A) {
     const int tid = threadIdx.x;
     const int li = tid % TI, tj = tid / TI, lj0 = PJ * tj;
     const int tilesPerImg = A.nTi * A.nTj;
-    const int img = blockIdx.x / tilesPerImg;
-    const int t = blockIdx.x - img * tilesPerImg;
+    const int imgl = blockIdx.x / tilesPerImg;
+    const int img = A.img0 + imgl;
+    const int t = blockIdx.x - imgl * tilesPerImg;
     const int ta = t % A.nTi, tb = t / A.nTi;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
