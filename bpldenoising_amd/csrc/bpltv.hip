@@ -783,8 +783,12 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                     };
                     {
                         std::vector<std::thread> th;
-                        for (size_t c = 1; c < ex.size(); ++c) th.emplace_back(launch_chain, c);
+                        std::vector<size_t> inline_chains;
+                        for (size_t c = 1; c < ex.size(); ++c) {
+                            try { th.emplace_back(launch_chain, c); } catch (...) { inline_chains.push_back(c); }   // no thread: launch from here
+                        }
                         launch_chain(0);
+                        for (size_t c : inline_chains) launch_chain(c);
                         for (auto& t : th) t.join();
                     }
                     for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, cerr[c]);
@@ -1541,14 +1545,17 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
                     h->chain_events.push_back(ce);
                 }
                 hipError_t e1 = hipSuccess;
-                std::thread th([&]() {
+                auto launch1 = [&]() {
                     e1 = hipSetDevice(h->device);
                     if (e1 == hipSuccess) e1 = hipStreamWaitEvent(h->chain_streams[0], h->ev[0], 0);
                     if (e1 == hipSuccess) e1 = hipGraphLaunch(exs[1], h->chain_streams[0]);
                     if (e1 == hipSuccess) e1 = hipEventRecord(h->chain_events[0], h->chain_streams[0]);
-                });
+                };
+                std::thread th;
+                bool threaded = true;
+                try { th = std::thread(launch1); } catch (...) { threaded = false; }
                 const hipError_t e0 = hipGraphLaunch(exs[0], h->stream);
-                th.join();
+                if (threaded) th.join(); else launch1();
                 HIPCHK(h, e0);
                 HIPCHK(h, e1);
                 HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[0], 0));
