@@ -518,13 +518,13 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
     int ch = p.reserved[1];
     if (ch <= 0) {
-        // Two chains once the batch no longer fits the chip with one workgroup per CU: the second chain's kernels run in
+        // Two chains once the batch is well beyond one workgroup per CU: the second chain's kernels run in
         // the first one's launch gaps (10 x 128^2: 7.2e5 -> 8.5e5 it/s; 8 / 32 / 64 images +18 / 26 / 16 %; the large-image
         // workloads +2 %).  Smaller batches are faster as one chain (2-5 images: -3 ... -10 % with two).  Chain 0 runs on
         // the handle's own stream, chain 1 on a second one: those two hardware queues overlap; a third does not (it shares
         // a pipe with the second: 3 chains 7.8e5) -- DESIGN.md section 4.1.
         const int ncu = h->ncu > 0 ? h->ncu : 256;
-        ch = (pl->grid > ncu && h->cur_nimg >= 2) ? 2 : 1;
+        ch = (2 * pl->grid > 3 * ncu && h->cur_nimg >= 2) ? 2 : 1;   // from 1.5 workgroups per CU (6 / 7 images of 128^2: +1.5 / -8.5 % with two chains)
     }
     if (ch > h->cur_nimg) ch = h->cur_nimg;
     pl->chains = ch;
@@ -1497,7 +1497,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     // two launch chains (image groups) as in run_pdhg: chain 0 on the handle's stream, chain 1 on a second one, half a
     // launch out of phase; reserved[1] = 1 keeps one chain
     const int h0 = std::max(1, T / 2);
-    int nch = p.reserved[1] > 0 ? std::min(p.reserved[1], 2) : ((grid > (h->ncu > 0 ? h->ncu : 256) && h->O >= 2) ? 2 : 1);
+    int nch = p.reserved[1] > 0 ? std::min(p.reserved[1], 2) : ((2 * grid > 3 * (h->ncu > 0 ? h->ncu : 256) && h->O >= 2) ? 2 : 1);
     if (nch > h->O) nch = h->O;
     const bool stag = T >= 2 && nl >= 8 && ((1 + (p.maxiter - h0 + T - 1) / T) - nl) % 2 == 1;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
