@@ -531,6 +531,13 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     return BPLTV_OK;
 }
 
+// May an odd launch chain run half a launch out of phase (first launch T/2 iterations, one launch more, starting in the
+// other state set)?  Only when that leaves it in the same final set as the even chains, and for long sequences.
+bool chain_out_of_phase(int niter, int T, bool from_state) {
+    const int nl0 = (niter + T - 1) / T, h0 = T / 2;
+    return !from_state && T >= 2 && nl0 >= 8 && ((1 + (niter - h0 + T - 1) / T) - nl0) % 2 == 1;
+}
+
 // Build one hipGraph per chain (image group): maxiter iterations as a linear launch sequence.
 // The chains are replayed concurrently, each on its own stream (= its own hardware queue).
 int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double* d_tab, int niter, bool from_state,
@@ -549,8 +556,8 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         // launch gaps fall into the other chain's arithmetic instead of both idling and both computing together (chains
         // of equal size otherwise stay in lockstep).  Such a chain has one launch more; it starts by writing set 1, so
         // that every chain ends in the same set.  Results do not depend on how the iterations are cut into launches.
-        const int nl0 = (niter + pl.T - 1) / pl.T, h0 = pl.T / 2;
-        const bool stagger = (c & 1) && !from_state && pl.T >= 2 && nl0 >= 8 && ((1 + (niter - h0 + pl.T - 1) / pl.T) - nl0) % 2 == 1;
+        const int h0 = pl.T / 2;
+        const bool stagger = (c & 1) && chain_out_of_phase(niter, pl.T, from_state);
         int step = stagger ? h0 : pl.T;
         for (int it = 0; it < niter; it += step, step = pl.T) {
             PdhgArgs a;
@@ -796,7 +803,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                         HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[c - 1], 0));
                 }
                 buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
-                launches = nl * (int)ex.size();
+                launches = nl * (int)ex.size() + (chain_out_of_phase(main_iters, pl.T, from_state) ? (int)ex.size() / 2 : 0);
                 h->st.graph_used = 1;
                 done = true;
             }

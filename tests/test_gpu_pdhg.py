@@ -52,6 +52,41 @@ def test_every_kernel_variant_and_fusion_depth_is_bit_identical(gpu_solver_cls, 
     s.close()
 
 
+def test_launch_chains_out_of_phase_are_bit_identical(gpu_solver_cls, oracle):
+    """Two launch chains (image groups on two streams), the second half a launch out of phase: its first launch fuses
+    T/2 iterations and writes the other state set (only when that leaves every chain in the same set: iteration counts
+    that are multiples of T, e.g. the reference's 5000).  Same bits as one chain and as the oracle; explicit and default
+    (a batch beyond 1.5 workgroups per CU), the tile and the rows kernel, also for the sum of regularisers."""
+    O, N, M = 12, 128, 128
+    ub, f = synth_batch(O, N, M, seed=8)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    for maxiter, T_ in ((96, 8), (200, 8), (120, 6), (97, 8)):
+        u0 = oracle.pdhg(f, 0.08, maxiter=maxiter, nthreads=8)
+        for chains in (0, 1, 2):
+            u = s.denoise(0.08, maxiter=maxiter, tile_iters=T_, chains=chains)
+            st = s.stats()
+            assert np.array_equal(u, u0), (maxiter, T_, chains)
+            nl = -(-maxiter // T_)
+            if chains != 1:
+                assert st["launches"] in (2 * nl, 2 * nl + 1), st       # two chains; + 1 launch when out of phase
+                assert (st["launches"] == 2 * nl + 1) == (maxiter % T_ == 0)
+    a3 = np.array([0.03, 0.02, 0.05])
+    us = s.sumregs_denoise(a3, maxiter=96, variant=1)                 # 588 tiles of 32 x 32: two chains
+    assert s.stats()["launches"] == 2 * 24 + 1
+    assert np.array_equal(us, s.sumregs_denoise(a3, maxiter=96, variant=1, chains=1))
+    s.close()
+    O, N, M = 6, 300, 260                     # rows kernel, 2 x 150 tiles
+    ub, f = synth_batch(O, N, M, seed=9)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u1 = s.denoise(0.1, maxiter=64, chains=1)
+    u2 = s.denoise(0.1, maxiter=64, chains=2)
+    assert s.stats()["pdhg_variant"] in (19, 20) and s.stats()["launches"] == 2 * 8 + 1
+    assert np.array_equal(u1, u2) and np.array_equal(u1, oracle.pdhg(f, 0.1, maxiter=64, nthreads=8))
+    s.close()
+
+
 @pytest.mark.parametrize("ds,lo,hi,alpha,maxiter,name", [
     ("faces_train_128_10", 0, 10, 0.07, 5000, "faces_train_scalar"),
     ("cameraman_128_10", 0, 1, P22 * 0 + np.array([[0.08, 0.12], [0.1, 0.05]]), 5000, "cameraman10_patch22"),
