@@ -1418,17 +1418,19 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (p.reserved[0] < 0 || p.reserved[0] > SR_NVARIANTS) return set_err(h, BPLTV_E_ARG, "variant %d: the sum-of-regularisers model has 1..%d", p.reserved[0], SR_NVARIANTS);
     int vi = p.reserved[0] - 1;
     if (vi < 0) {
-        // Both kernels are VALU-issue bound.  One launch of T = 4 iterations costs about 16 us with two
-        // 32 x 32 workgroups per CU and about 20 us with the one 48 x 48 workgroup a CU holds; the 48 x 48 region
-        // recomputes 2.25 x instead of 4 x.  Rounds of workgroups over the CUs decide: the small batch (10 x 128^2:
-        // 490 tiles against 160 on 256 CUs) stays with the one-pixel kernel, anything of a few 256^2 images up goes
-        // to the strip kernel.
+        // Both kernels are VALU-issue bound; the 48 x 48 region recomputes 2.25 x instead of 4 x but holds one
+        // workgroup per CU.  Fitted on MI355X with the two launch chains in place (ms per 1000 iterations at T = 4,
+        // gpurun_out/r3s, 10 ... 40 images of 128^2, 8 x 200^2, 3 ... 6 x 256^2, 4 x 512^2, 2 x 1024^2): the one-pixel kernel
+        // 0.6 + 0.0056 per 32 x 32 tile; the strip kernel 5.0 while every CU holds at most one 48 x 48 workgroup, 9.1 for
+        // a second round, then 0.0157 per tile.  The strip kernel takes over from about 40 images of 128^2 or 4 of 256^2.
         const int ncu = h->ncu > 0 ? h->ncu : 256;
         auto tiles = [&](int R) {
             const int Tt = std::max(1, std::min(4, std::min((M <= R) ? 4 : (R - 1) / 4, (N <= R) ? 4 : (R - 1) / 4)));
             return (double)tile_count(M, R, 2 * Tt) * tile_count(N, R, 2 * Tt) * h->O;
         };
-        const double c32 = 16.0 * std::ceil(tiles(32) / (2.0 * ncu)), c48 = 20.0 * std::ceil(tiles(48) / (1.0 * ncu));
+        const double t32 = tiles(32), t48 = tiles(48);
+        const double c32 = 0.6 + 0.0056 * t32;
+        const double c48 = t48 <= ncu ? 5.0 : (t48 <= 2 * ncu ? 9.1 : std::max(9.1, 0.0157 * t48));
         vi = (M <= 32 && N <= 32) ? 0 : (c48 < c32 ? 1 : 0);
     }
     const SrVariant& V = SR_VARIANTS[vi];
