@@ -49,10 +49,17 @@ struct Variant {
     int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel)
 };
 
+// grid of a launch of `tiles` tiles: (nTi, nTj, images) when the kernel decodes blockIdx that way (PdhgArgs::grid3d)
+inline dim3 pdhg_grid(const PdhgArgs& a, int tiles) {
+    return a.grid3d ? dim3(a.nTi, a.nTj, tiles / (a.nTi * a.nTj)) : dim3(tiles);
+}
+// whether a launch of `nimg` images can use the 3-D grid (one tile per workgroup, grid.y / grid.z limits)
+inline int pdhg_grid3d_ok(int nTj, int nimg, int tiles_per_block) { return (tiles_per_block == 1 && nTj <= 65535 && nimg <= 65535) ? 1 : 0; }
+
 template <typename T, int PI, int PJ, int TI, int TJ>
 void launch_variant(const PdhgArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = pdhg_lds_bytes(PI * TI, PJ * TJ, sizeof(T));
-    hipLaunchKernelGGL((pdhg_tile_kernel<T, PI, PJ, TI, TJ>), dim3(grid), dim3(TI * TJ), lds, s, a);
+    hipLaunchKernelGGL((pdhg_tile_kernel<T, PI, PJ, TI, TJ>), pdhg_grid(a, grid), dim3(TI * TJ), lds, s, a);
 }
 
 #define VAR(PI, PJ, TI, TJ)                                                                    \
@@ -75,7 +82,7 @@ void launch_wave_variant(const PdhgArgs& a, int grid, hipStream_t s) {
 // 64-lane rows, PJ pixels per thread along j, TJ waves (pdhg_rows_kernel): region 64 x (PJ * TJ); CL: f and alpha in LDS
 template <typename T, int PJ, int TJ, bool CL>
 void launch_rows_variant(const PdhgArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((pdhg_rows_kernel<T, PJ, TJ, CL>), dim3(grid), dim3(64 * TJ), pdhg_rows_lds(PJ, TJ, CL, sizeof(T)), s, a);
+    hipLaunchKernelGGL((pdhg_rows_kernel<T, PJ, TJ, CL>), pdhg_grid(a, grid), dim3(64 * TJ), pdhg_rows_lds(PJ, TJ, CL, sizeof(T)), s, a);
 }
 #define VARR(PJ, TJ, CL)                                                                        \
     { 64, PJ * TJ, 64 * TJ, &launch_rows_variant<double, PJ, TJ, CL>,                           \
@@ -581,7 +588,8 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             std::memset(&kp, 0, sizeof(kp));
             kp.func = const_cast<void*>(h->dtype == 32 ? V.func32 : V.func);
             a.ntiles = tilesPerImg * (hi - lo);
-            kp.gridDim = dim3((tilesPerImg * (hi - lo) + V.tiles_per_block - 1) / V.tiles_per_block);
+            a.grid3d = pdhg_grid3d_ok(pl.nTj, hi - lo, V.tiles_per_block);
+            kp.gridDim = a.grid3d ? pdhg_grid(a, a.ntiles) : dim3((tilesPerImg * (hi - lo) + V.tiles_per_block - 1) / V.tiles_per_block);
             kp.blockDim = dim3(V.threads);
             kp.sharedMemBytes = (unsigned)(h->dtype == 32 ? V.lds32 : V.lds);
             kp.kernelParams = kargs;
@@ -627,6 +635,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
     a.img0 = 0;
     a.ntiles = pl.grid;
+    a.grid3d = pdhg_grid3d_ok(pl.nTj, h->cur_nimg, V.tiles_per_block);
 #ifdef BPLTV_EXPERIMENTS
     a.dbg = p.reserved[3];
 #endif

@@ -51,6 +51,8 @@ struct PdhgArgs {
                 // parameter block alpha + (img / Odata) * astride (parameter sweeps: K*Odata problems)
     int astride;
     int ntiles; // tiles of this launch (pdhg_wave_kernel: several tiles per workgroup, the last one may be short)
+    int grid3d; // 1: the grid is (nTi, nTj, images): tile and image come from blockIdx.x / .y / .z and the kernel's prologue
+                // needs no integer division (4 of them, ~100 scalar instructions per wave, with the 1-D grid)
 #ifdef BPLTV_EXPERIMENTS
     int dbg;    // timing experiments of tools/ builds only (results are wrong): 1 skip state loads, 2 skip
                 // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads.  The product
@@ -63,6 +65,23 @@ struct PdhgArgs {
 #else
 #define BPLTV_DBG(A) 0
 #endif
+
+// Tile (ta, tb) and image of the launch (imgl) of this workgroup; dataset image and parameter block of a solve image
+// (parameter sweeps run K * Odata problems: image `img` uses f[img % Odata] and parameter block img / Odata).
+#define PDHG_DECODE_BLOCK(A, imgl, ta, tb)                                   \
+    int imgl, ta, tb;                                                        \
+    if ((A).grid3d) {                                                        \
+        ta = (int)blockIdx.x; tb = (int)blockIdx.y; imgl = (int)blockIdx.z;  \
+    } else {                                                                 \
+        const int tilesPerImg_ = (A).nTi * (A).nTj;                          \
+        imgl = (int)blockIdx.x / tilesPerImg_;                               \
+        const int t_ = (int)blockIdx.x - imgl * tilesPerImg_;                \
+        ta = t_ % (A).nTi; tb = t_ / (A).nTi;                                \
+    }
+__device__ __forceinline__ void pdhg_data_image(int img, int O, int Odata, int& fimg, int& apar) {
+    if (O == Odata) { fimg = img; apar = 0; }        // no sweep: the solve images are the dataset's
+    else { fimg = img % Odata; apar = img / Odata; }
+}
 
 // 1-D tiling with halo: region length R, halo T, image length L.  Tile a covers region
 // [o, o+R) and owns (writes back) the core [c0, c1).  Image borders need no halo (Neumann).
@@ -173,18 +192,17 @@ __global__ __launch_bounds__(TI* TJ) void pdhg_tile_kernel(PdhgArgs A) {
 
     const int tid = threadIdx.x;
     const int ti = tid % TI, tj = tid / TI;
-    const int tilesPerImg = A.nTi * A.nTj;
-    const int imgl = blockIdx.x / tilesPerImg;
+    PDHG_DECODE_BLOCK(A, imgl, ta, tb)
     const int img = A.img0 + imgl;
-    const int t = blockIdx.x - imgl * tilesPerImg;
-    const int ta = t % A.nTi, tb = t / A.nTi;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
     const int M = A.M, N = A.N;
+    int fimg, apar;
+    pdhg_data_image(img, A.O, A.Odata, fimg, apar);
     const size_t base = (size_t)img * M * N;                 // state planes: one slot per solve image
-    const size_t fbase = (size_t)(img % A.Odata) * M * N;    // dataset planes
-    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)(img / A.Odata) * A.astride;
+    const size_t fbase = (size_t)fimg * M * N;               // dataset planes
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
     const bool first = (A.first != 0) || (BPLTV_DBG(A) & 1);
 
@@ -495,18 +513,17 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
     const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
     const int tid = threadIdx.x, ti = tid & 63;
     const int tj = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: uniform
-    const int tilesPerImg = A.nTi * A.nTj;
-    const int imgl = blockIdx.x / tilesPerImg;
+    PDHG_DECODE_BLOCK(A, imgl, ta, tb)
     const int img = A.img0 + imgl;
-    const int t = blockIdx.x - imgl * tilesPerImg;
-    const int ta = t % A.nTi, tb = t / A.nTi;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
     const int M = A.M, N = A.N;
+    int fimg, apar;
+    pdhg_data_image(img, A.O, A.Odata, fimg, apar);
     const size_t base = (size_t)img * M * N;
-    const size_t fbase = (size_t)(img % A.Odata) * M * N;
-    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)(img / A.Odata) * A.astride;
+    const size_t fbase = (size_t)fimg * M * N;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
     const bool first = A.first != 0;
     const int lj0 = PJ * tj;
