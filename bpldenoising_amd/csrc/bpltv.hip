@@ -1421,6 +1421,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     double* d_tab = nullptr;
     if (p.init != 0 || p.order != 0)
         return set_err(h, BPLTV_E_UNSUPPORTED, "params.init / params.order are implemented for the TV model only");
+    if (h->O > 65535) return set_err(h, BPLTV_E_UNSUPPORTED, "the sum-of-regularisers solve takes at most 65535 images per handle (images are a grid dimension)");
     rc = get_table(h, p, &d_tab, 18.0);   // ||G_f||^2 + ||G_b||^2 + ||G_c||^2 <= 8 + 8 + 2 (sumregs_oracle.c: SR_L)
     if (rc) return rc;
     const int M = h->M, N = h->N;
@@ -1474,7 +1475,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
             a.M = M; a.N = N; a.O = h->O; a.nTi = nTi; a.nTj = nTj; a.halo = 2 * T;
             a.first = (it == 0) ? 1 : 0;
             a.img0 = lo;
-            hipLaunchKernelGGL(V.kernel, dim3(nTi * nTj * (hi - lo)), dim3(V.threads), V.lds, st, a);
+            hipLaunchKernelGGL(V.kernel, dim3(nTi, nTj, hi - lo), dim3(V.threads), V.lds, st, a);
             cur = nxt;
         }
         return cur;

@@ -50,11 +50,9 @@ __global__ __launch_bounds__(TI* TJ) void sr_tile_kernel(SrArgs A) {
     double* sxb = smem + 6 * RN;
     const int tid = threadIdx.x;
     const int li = tid % TI, lj = tid / TI;
-    const int tilesPerImg = A.nTi * A.nTj;
-    const int imgl = blockIdx.x / tilesPerImg;
-    const int img = A.img0 + imgl;
-    const int t = blockIdx.x - imgl * tilesPerImg;
-    const int ta = t % A.nTi, tb = t / A.nTi;
+    // grid (nTi, nTj, images of the chain): tile and image without an integer division
+    const int ta = (int)blockIdx.x, tb = (int)blockIdx.y;
+    const int img = A.img0 + (int)blockIdx.z;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
@@ -188,11 +186,9 @@ __global__ __launch_bounds__(TI* TJ) void sr_strip_kernel(SrArgs A) {
     double* sxb = smem + 6 * RN;
     const int tid = threadIdx.x;
     const int li = tid % TI, tj = tid / TI, lj0 = PJ * tj;
-    const int tilesPerImg = A.nTi * A.nTj;
-    const int imgl = blockIdx.x / tilesPerImg;
-    const int img = A.img0 + imgl;
-    const int t = blockIdx.x - imgl * tilesPerImg;
-    const int ta = t % A.nTi, tb = t / A.nTi;
+    // grid (nTi, nTj, images of the chain): tile and image without an integer division
+    const int ta = (int)blockIdx.x, tb = (int)blockIdx.y;
+    const int img = A.img0 + (int)blockIdx.z;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
     tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
