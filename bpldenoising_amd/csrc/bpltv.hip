@@ -491,7 +491,10 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
                 // whole rounds for the short tile workgroups; the long rows workgroups overlap the tail of a round
                 const double eff = Vc.min_image ? (rounds <= 1.0 ? 1.0 : 0.5 * (std::ceil(rounds) + rounds)) : std::ceil(rounds);
                 const double per_iter = (tiles <= ncu) ? cd.one : cd.two * eff;
-                const double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
+                double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
+                // two launch chains (below: from 1.5 workgroups per CU) hide part of every launch of the 32x32 kernel:
+                // 10 images at T = 8 and 5 images at T = 10 take 0.74 / 0.69 of what the single-chain model says
+                if (cd.v == 0 && p.reserved[1] != 1 && h->cur_nimg >= 2 && 2.0 * tiles > 3.0 * ncu) cost *= 0.72;
                 if (cost < best) { best = cost; T = t; v = cd.v; }
             }
         }
