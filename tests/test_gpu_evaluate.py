@@ -511,15 +511,18 @@ def test_config5_share_evaluate_8x1024(gpu_solver_cls):
     s.close()
 
 
-def test_large_batch_uses_the_wide_region_plan(gpu_solver_cls, oracle):
-    """From about 12 images of 128^2 the automatic plan switches to 48x48 regions (3 px per thread): same bits."""
-    ub, f = synth_batch(16, 128, 128, seed=90)
-    s = gpu_solver_cls(128, 128, 16)
+@pytest.mark.parametrize("O", [16, 40])
+def test_larger_batches_of_small_images_same_bits_whatever_the_plan(gpu_solver_cls, oracle, O):
+    """Batches beyond the reference's ten images: the launch-cost model moves between the 32x32 kernel with two launch
+    chains, 48x48 regions (3 px per thread) and the 64-lane rows kernels as the batch grows; whatever it picks, same bits."""
+    ub, f = synth_batch(O, 128, 128, seed=90)
+    s = gpu_solver_cls(128, 128, O)
     s.set_data(ub, f)
     u = s.denoise(0.07, maxiter=300)
     st = s.stats()
-    assert st["tiles"] == 16 * 16 and st["tile_iters"] == 10          # 4 x 4 tiles of 48x48 per image
+    assert st["region_i"] in (32, 48, 64) and 2 <= st["tile_iters"] <= 12 and st["graph_used"] == 1, st
     assert np.array_equal(u, oracle.pdhg(f, 0.07, maxiter=300, nthreads=8))
+    assert np.array_equal(u, s.denoise(0.07, maxiter=300, variant=13, tile_iters=10, chains=1))      # the 48x48 plan explicitly
     s.close()
 
 
