@@ -281,6 +281,11 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
             "avg_kernel_us_serialized": kernel_us,
             "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
             "launch_chains": chains,   # concurrent chains of image groups: avg_launch_us = whole time / all dispatches
+            "overlap_note": (None if chains == 1 else
+                             "%d launch chains run concurrently on two hardware queues: a rocprofv3 kernel trace shows ~%d kernels in flight, "
+                             "each about avg_kernel_us_serialized long (a little longer while overlapped), so dispatches x kernel duration / %d ~ the step time; "
+                             "`achieved` / `frac` use the whole-chip time per dispatch (avg_launch_us), `frac_isolated_kernel` the duration of one kernel alone"
+                             % (chains, chains, chains)),
             "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
             "bytes_per_px_iter": bytes_px}
 
