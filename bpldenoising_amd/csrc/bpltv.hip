@@ -494,7 +494,10 @@ int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
                 double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
                 // two launch chains (below: from 1.5 workgroups per CU) hide part of every launch of the 32x32 kernel:
                 // 10 images at T = 8 and 5 images at T = 10 take 0.74 / 0.69 of what the single-chain model says
-                if (cd.v == 0 && p.reserved[1] != 1 && h->cur_nimg >= 2 && 2.0 * tiles > 3.0 * ncu) cost *= 0.72;
+                // (only within one round of workgroups: with several rounds every round pays its own prologue and state
+                //  round trip and the discount misleads -- 32 ... 64 images, 6 / 10 x 256^2 were 7-33 % slower with it; and
+                //  not for shallow fusion, where that per-round cost dominates: 4 x 256^2 at T = 4 was 13 % slower)
+                if (cd.v == 0 && p.reserved[1] != 1 && h->cur_nimg >= 2 && 2.0 * tiles > 3.0 * ncu && tiles <= 2.0 * ncu && t >= 6) cost *= 0.72;
                 if (cost < best) { best = cost; T = t; v = cd.v; }
             }
         }
