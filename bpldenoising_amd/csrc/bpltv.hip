@@ -807,6 +807,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                         std::vector<std::thread> th;
                         std::vector<size_t> inline_chains;
                         for (size_t c = 1; c < ex.size(); ++c) {
+                            if (nl < 128) { inline_chains.push_back(c); continue; }   // short sequences: a helper thread costs more than it hides
                             try { th.emplace_back(launch_chain, c); } catch (...) { inline_chains.push_back(c); }   // no thread: launch from here
                         }
                         launch_chain(0);
@@ -1577,8 +1578,10 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
                     if (e1 == hipSuccess) e1 = hipEventRecord(h->chain_events[0], h->chain_streams[0]);
                 };
                 std::thread th;
-                bool threaded = true;
-                try { th = std::thread(launch1); } catch (...) { threaded = false; }
+                bool threaded = nl >= 128;   // short sequences: a helper thread costs more than it hides
+                if (threaded) {
+                    try { th = std::thread(launch1); } catch (...) { threaded = false; }
+                }
                 const hipError_t e0 = hipGraphLaunch(exs[0], h->stream);
                 if (threaded) th.join(); else launch1();
                 HIPCHK(h, e0);
