@@ -71,6 +71,9 @@ def test_launch_chains_out_of_phase_are_bit_identical(gpu_solver_cls, oracle):
             if chains != 1:
                 assert st["launches"] in (2 * nl, 2 * nl + 1), st       # two chains; + 1 launch when out of phase
                 assert (st["launches"] == 2 * nl + 1) == (maxiter % T_ == 0)
+    for init, order in ((1, 0), (0, 1), (1, 1)):      # prepared starts: two chains in phase (they begin in state set 1)
+        u = s.denoise(0.08, maxiter=96, tile_iters=8, init=init, order=order)
+        assert np.array_equal(u, oracle.pdhg_opts(f, 0.08, maxiter=96, init=init, order=order)), (init, order)
     a3 = np.array([0.03, 0.02, 0.05])
     us = s.sumregs_denoise(a3, maxiter=96, variant=1)                 # 588 tiles of 32 x 32: two chains
     assert s.stats()["launches"] == 2 * 24 + 1
