@@ -486,17 +486,21 @@ __global__ __launch_bounds__(BG_T) void nd_schur_kernel(NdArgs A) {
 // kept in the diagonal slot of both triangles.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int NDG_T = 1024;
-inline size_t nd_getri_lds() { return sizeof(double) * HB2_NB * (HB2_NB + 1); }
+inline size_t nd_getri_lds() { return 0; }   // static LDS only (the block is held in registers)
 // A pivot that is zero, not finite, or has lost every digit against the diagonal entry it started from means the
 // elimination without pivoting has broken down (hb_getri_kernel's criterion).
 __device__ __forceinline__ bool nd_lu_pivot_bad(double piv, double d0) { return !(fabs(piv) > 2.220446049250313e-16 * d0 && fabs(piv) < 1.7e308); }
 
-// Inverse of the diagonal block of pivot panel k by Gauss-Jordan elimination without pivoting, in LDS; its transpose
-// replaces the block in both triangles.  A.fac = FL, A.fac2 = FU.  grid (nodes, nimg), block NDG_T, LDS nd_getri_lds().
+// Inverse of the diagonal block of pivot panel k by Gauss-Jordan elimination without pivoting; its transpose replaces the
+// block in both triangles.  A.fac = FL, A.fac2 = FU.  The 128 x 128 block lives in REGISTERS: thread (column j = tid & 127,
+// row group g = tid >> 7) owns rows g + 8 m of column j.  A step needs the pivot row and the pivot column only: their
+// owners publish them in two LDS vectors (double-buffered: one barrier per step), everybody else reads one pivot-row
+// entry and -- as a wave-wide broadcast -- the sixteen pivot-column entries of its rows.  (The first version kept the
+// matrix in LDS and moved 3 x 128 KB per step: 196 us per block against ~45 us.)  grid (nodes, nimg), block NDG_T.
 __global__ __launch_bounds__(NDG_T) void nd_getri_kernel(NdArgs A, int k) {
-    extern __shared__ double S[];
-    __shared__ double d0[HB2_NB];
-    constexpr int MP = HB2_NB, ld = MP + 1;
+    __shared__ double rowb[2][HB2_NB], colb[2][HB2_NB], d0[HB2_NB];
+    __shared__ int badk_s;
+    constexpr int MP = HB2_NB;
     const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const NdNodeDev v = A.nodes[node];
     const int p = v.p, f = p + v.b, c0 = HB2_NB * k;
@@ -504,40 +508,57 @@ __global__ __launch_bounds__(NDG_T) void nd_getri_kernel(NdArgs A, int k) {
     const int nb = min(HB2_NB, p - c0);
     double* bL = A.fac + (size_t)img * A.fac_stride + v.fac_off + c0 + (size_t)f * c0;
     double* bU = A.fac2 + (size_t)img * A.fac_stride + v.fac_off + c0 + (size_t)f * c0;
-    for (int e = tid; e < MP * MP; e += NDG_T) {
-        const int r = e % MP, c = e / MP;
-        double x = (r == c) ? 1.0 : 0.0;   // identity padding
-        if (r < nb && c < nb) x = (r >= c) ? bL[r + (size_t)f * c] : bU[c + (size_t)f * r];
-        S[r + ld * c] = x;
-        if (r == c) d0[r] = fabs(x);
-    }
-    __syncthreads();
-    const int j = tid & (MP - 1), i0 = tid >> 7;   // thread: column j, rows i0 + 8 m
-    int badk = -1;
-    for (int kk = 0; kk < nb; ++kk) {
-        const double piv = S[kk + ld * kk];
-        if (badk < 0 && nd_lu_pivot_bad(piv, d0[kk])) badk = kk;
-        const double pinv = 1.0 / piv;
-        const double rk = (j == kk) ? pinv : S[kk + ld * j] * pinv;
-        double nv[16];
+    const int j = tid & (MP - 1);
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 7);   // row group: uniform over a wave
+    double a[16];
 #pragma unroll
-        for (int mq = 0; mq < 16; ++mq) {
-            const int i = i0 + 8 * mq;
-            const double fi = S[i + ld * kk];
-            const double old = (j == kk) ? 0.0 : S[i + ld * j];
-            nv[mq] = (i == kk) ? rk : old - fi * rk;
+    for (int m = 0; m < 16; ++m) {
+        const int i = g + 8 * m;
+        double x = (i == j) ? 1.0 : 0.0;   // identity padding
+        if (i < nb && j < nb) x = (i >= j) ? bL[i + (size_t)f * j] : bU[j + (size_t)f * i];
+        a[m] = x;
+        if (i == j) d0[i] = fabs(x);
+        if (i == 0) rowb[0][j] = x;
+        if (j == 0) { colb[0][i] = x; a[m] = 0.0; }   // a pivot column lives on in its published copy: the in-place
+                                                     // inverse starts that column from zero
+    }
+    if (tid == 0) badk_s = -1;
+    __syncthreads();
+    for (int kk = 0; kk < nb; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        const double piv = rowb[cur][kk];
+        // a pivot that is zero, not finite or has lost every digit against its original diagonal entry: broken down
+        if (tid == 0 && badk_s < 0 && nd_lu_pivot_bad(piv, d0[kk])) badk_s = kk;
+        double pinv = __builtin_amdgcn_rcp(piv);              // 1 / piv by two Newton steps on the hardware estimate
+        pinv = __builtin_fma(__builtin_fma(-piv, pinv, 1.0), pinv, pinv);
+        pinv = __builtin_fma(__builtin_fma(-piv, pinv, 1.0), pinv, pinv);
+        const double rk = (j == kk) ? pinv : rowb[cur][j] * pinv;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a[m] = __builtin_fma(-colb[cur][g + 8 * m], rk, a[m]);   // column reads: wave-wide broadcasts
+        if (g == (kk & 7)) {          // the waves that hold the pivot row: it becomes rk
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m == (kk >> 3)) a[m] = rk;
+        }
+        if (g == ((kk + 1) & 7)) {    // ... and those that hold the next pivot row publish it
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m == ((kk + 1) >> 3)) rowb[nxt][j] = a[m];
+        }
+        if (j == kk + 1) {            // the next pivot column: publish, then restart it from zero
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { colb[nxt][g + 8 * m] = a[m]; a[m] = 0.0; }
         }
         __syncthreads();
-#pragma unroll
-        for (int mq = 0; mq < 16; ++mq) S[i0 + 8 * mq + ld * j] = nv[mq];
-        __syncthreads();
     }
-    if (badk >= 0 && tid == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
-    for (int e = tid; e < nb * nb; e += NDG_T) {
-        const int r = e % nb, c = e / nb;
-        const double x = S[c + ld * r];   // slot(r, c) = D^-1(c, r)
-        bL[r + (size_t)f * c] = x;
-        bU[r + (size_t)f * c] = x;
+    if (tid == 0 && badk_s >= 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = g + 8 * m;
+        if (i < nb && j < nb) {   // slot(r, c) = D^-1(c, r): this thread's D^-1(i, j) goes to slot (j, i)
+            bL[j + (size_t)f * i] = a[m];
+            bU[j + (size_t)f * i] = a[m];
+        }
     }
 }
 

@@ -80,6 +80,7 @@ sumregs)
   python3 tools/gpu_sumregs_time.py > $OUT/sumregs_time.log 2>&1 || { tail -20 $OUT/sumregs_time.log; exit 1; }
   python3 tools/gpu_sumregs_large.py > $OUT/sumregs_large.log 2>&1 || { tail -20 $OUT/sumregs_large.log; exit 1; }
   grep -v amdgpu $OUT/sumregs_time.log
+  kt kt_sumregs python3 tools/gpu_sumregs_time.py
   ;;
 esac
 done

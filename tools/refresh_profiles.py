@@ -104,7 +104,7 @@ def publish(tag):
     copied = []
     for sub, name in (("kt_bench", "kernel_stats_bench"), ("kt_cfg5", "kernel_stats_cfg5_pdhg"),
                       ("kt_eval128", "kernel_stats_evaluate_128"), ("kt_evalcfg5", "kernel_stats_cfg5_evaluate"),
-                      ("kt_nd", "kernel_stats_nd_unit_1024x8")):
+                      ("kt_nd", "kernel_stats_nd_unit_1024x8"), ("kt_sumregs", "kernel_stats_sumregs")):
         ks = newest(os.path.join(sub, "**", "*kernel_stats.csv"))
         if ks:
             shutil.copy(ks, os.path.join(PRO, "%s_%s.csv" % (tag, name))); copied.append(name)
