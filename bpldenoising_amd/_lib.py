@@ -84,6 +84,7 @@ SYMBOLS = {
     "bpltv_gradient": (C.c_int, [_H, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _PP, _dp]),
     "bpltv_sweep": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_int, _PP, _dp, _dp]),
     "bpltv_per_image": (C.c_int, [_H, _dp]),
+    "bpltv_set_option": (C.c_int, [_H, C.c_char_p, C.c_double]),
     "bpltv_stats": (C.c_int, [_H, C.POINTER(BpltvStats)]),
     "bpltv_last_error": (C.c_char_p, [_H]),
 }

@@ -165,12 +165,25 @@ struct SrGraphKey {
 
 struct MultiState;   // shards, worker threads and the RCCL communicator of a multi-device handle (below)
 
+// bpltv_set_option (include/bpltv.h): aids for tests and measurements; nothing here changes a result.
+struct HandleOptions {
+    double adjoint_budget_mb = 0.0;   // > 0: HBM the adjoint's factor workspace may take (forces image groups)
+    int sr_force_lu = 0;              // 1: the LU variant of the nested dissection on the symmetric sum-of-regularisers systems too
+    int nd_leaf = 0;                  // > 0: leaf size (pixels) of the nested-dissection tree; 0 = 32
+    int hb_sync = 0;                  // HBM band cross-check solver: 0 automatic, 1 HIP events, 2 stream memory operations (fails if unavailable)
+    int hb_single_stream = 0;         // ... 1: its three streams folded into one (rocprofv3 --pmc)
+    int hb_rw = 0;                    // ... 32 / 128: row width of its trailing update (0 automatic)
+};
+
 struct bpltv_handle {
     MultiState* multi = nullptr;   // non-null: this handle only fans out to its shards (multi_gpu.hpp)
     int M = 0, N = 0, O = 0, device = 0, ncu = 0;
     size_t npx = 0, tot = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;   // what the launch chains wait for: everything enqueued on `stream` before the fork
+    std::unique_ptr<ShardWorker> launcher;   // persistent host thread that launches the second chain's graph (lazy)
+    HandleOptions opt;              // bpltv_set_option: test / measurement aids, all 0 = automatic
     bool has_data = false;
     // dataset + state
     double *d_ubar = nullptr, *d_f = nullptr;
@@ -690,6 +703,68 @@ int compute_gap(bpltv_t* h, double* gap_host /*O or null*/, double* gap_max_host
     return BPLTV_OK;
 }
 
+// Replay the launch chains of one solve: chain 0 on the handle's stream, chain c on chain_streams[c - 1], all forked
+// behind what the handle's stream holds now and joined back into it.  threaded: chain 1 is launched from the handle's
+// persistent launcher thread (worth it from ~128 launches; short sequences are launched from this thread).  Every
+// chain that was started is joined before an error is reported, so nothing is left running behind a failed call.
+int launch_chains(bpltv_t* h, const std::vector<hipGraphExec_t>& ex, bool threaded) {
+    while (h->chain_streams.size() + 1 < ex.size()) {   // chain 0 runs on the handle's own stream
+        hipStream_t cs = nullptr;
+        hipEvent_t ce = nullptr;
+        HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        if (hipEventCreateWithFlags(&ce, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(cs);
+            return set_err(h, BPLTV_E_HIP, "hipEventCreateWithFlags failed (launch chains)");
+        }
+        h->chain_streams.push_back(cs);
+        h->chain_events.push_back(ce);
+    }
+    HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
+    std::vector<hipError_t> cerr(ex.size(), hipSuccess);
+    std::vector<char> started(ex.size(), 0);
+    auto launch_chain = [&](size_t c) {
+        hipError_t e = hipSuccess;
+        if (c == 0) {
+            e = hipGraphLaunch(ex[0], h->stream);
+        } else {
+            hipStream_t cs = h->chain_streams[c - 1];
+            e = hipStreamWaitEvent(cs, h->fork_ev, 0);
+            if (e == hipSuccess) { started[c] = 1; e = hipGraphLaunch(ex[c], cs); }
+            if (e == hipSuccess) e = hipEventRecord(h->chain_events[c - 1], cs);
+        }
+        cerr[c] = e;
+    };
+    bool posted = false;
+    if (threaded && ex.size() >= 2) {
+        if (!h->launcher) {
+            try { h->launcher.reset(new ShardWorker(h->device)); } catch (...) { h->launcher.reset(); }
+        }
+        if (h->launcher) {
+            h->launcher->post([&launch_chain]() -> int { launch_chain(1); return 0; });
+            posted = true;
+        }
+    }
+    launch_chain(0);
+    for (size_t c = posted ? 2 : 1; c < ex.size(); ++c) launch_chain(c);
+    if (posted) (void)h->launcher->wait();
+    // join every chain that got as far as its stream, whatever happened to the others
+    hipError_t first = hipSuccess;
+    for (size_t c = 0; c < ex.size(); ++c) {
+        if (c >= 1 && started[c]) {
+            hipError_t e = (cerr[c] == hipSuccess) ? hipStreamWaitEvent(h->stream, h->chain_events[c - 1], 0)
+                                                   : hipStreamSynchronize(h->chain_streams[c - 1]);   // a half-launched chain: drain it
+            if (cerr[c] == hipSuccess) cerr[c] = e;
+        }
+        if (cerr[c] != hipSuccess && first == hipSuccess) first = cerr[c];
+    }
+    if (first != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
+        return set_err(h, BPLTV_E_HIP, "launch chains: %s", hipGetErrorString(first));
+    }
+    return BPLTV_OK;
+}
+
 int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     h->has_per_image = false;
     if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
@@ -779,44 +854,14 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                     // together) -- used by bench.py to time an isolated launch, as rocprofv3 sees it
                     for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, hipGraphLaunch(ex[c], h->stream));
                 } else {
-                    while (h->chain_streams.size() + 1 < ex.size()) {   // chain 0 runs on the handle's own stream
-                        hipStream_t cs = nullptr;
-                        hipEvent_t ce = nullptr;
-                        HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-                        HIPCHK(h, hipEventCreateWithFlags(&ce, hipEventDisableTiming));
-                        h->chain_streams.push_back(cs);
-                        h->chain_events.push_back(ce);
-                    }
-                    // fork: every chain waits for ev[0].  hipGraphLaunch walks the graph on the calling thread (a few
-                    // us of host time per kernel node), so the chains are launched from one host thread each --
-                    // launched one after the other from this thread the second chain starts when the first is
-                    // half done and nothing overlaps (measured: 6.83e5 it/s against 8.2e5 on the 10 x 128^2 batch).
-                    std::vector<hipError_t> cerr(ex.size(), hipSuccess);
-                    auto launch_chain = [&](size_t c) {
-                        hipError_t e = hipSetDevice(h->device);
-                        if (c == 0) {
-                            if (e == hipSuccess) e = hipGraphLaunch(ex[0], h->stream);
-                        } else {
-                            if (e == hipSuccess) e = hipStreamWaitEvent(h->chain_streams[c - 1], h->ev[0], 0);
-                            if (e == hipSuccess) e = hipGraphLaunch(ex[c], h->chain_streams[c - 1]);
-                            if (e == hipSuccess) e = hipEventRecord(h->chain_events[c - 1], h->chain_streams[c - 1]);
-                        }
-                        cerr[c] = e;
-                    };
-                    {
-                        std::vector<std::thread> th;
-                        std::vector<size_t> inline_chains;
-                        for (size_t c = 1; c < ex.size(); ++c) {
-                            if (nl < 128) { inline_chains.push_back(c); continue; }   // short sequences: a helper thread costs more than it hides
-                            try { th.emplace_back(launch_chain, c); } catch (...) { inline_chains.push_back(c); }   // no thread: launch from here
-                        }
-                        launch_chain(0);
-                        for (size_t c : inline_chains) launch_chain(c);
-                        for (auto& t : th) t.join();
-                    }
-                    for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, cerr[c]);
-                    for (size_t c = 1; c < ex.size(); ++c)  // join
-                        HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[c - 1], 0));
+                    // fork: every chain waits for what is on the handle's stream now (fork_ev is recorded behind
+                    // pdhg_init_kernel when the sequence starts from a prepared state; ev[0] -- the timing start -- sits in
+                    // front of it).  hipGraphLaunch walks the graph on the calling thread (a few us of host time per
+                    // kernel node), so the second chain is launched from the handle's launcher thread -- launched one after
+                    // the other from this thread the second chain starts when the first is half done and nothing
+                    // overlaps (measured: 6.83e5 it/s against 8.2e5 on the 10 x 128^2 batch).
+                    rc = launch_chains(h, ex, nl >= 128);
+                    if (rc) return rc;
                 }
                 buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
                 launches = nl * (int)ex.size() + (chain_out_of_phase(main_iters, pl.T, from_state) ? (int)ex.size() / 2 : 0);
@@ -923,11 +968,10 @@ int adj_alloc(bpltv_t* h) {
     return BPLTV_OK;
 }
 
-// HBM the factor workspace of the adjoint may take: BPLTV_ADJ_BUDGET_MB (a test aid: forces the gradient to run in
-// image groups), else what is free now plus what this handle already holds for it, minus a 2 GB reserve.
-size_t adj_budget(size_t held) {
-    const char* e = getenv("BPLTV_ADJ_BUDGET_MB");
-    if (e && atof(e) > 0.0) return (size_t)(atof(e) * 1e6);
+// HBM the factor workspace of the adjoint may take: bpltv_set_option "adjoint_budget_mb" (a test aid: forces the
+// gradient to run in image groups), else what is free now plus what this handle already holds for it, minus a 2 GB reserve.
+size_t adj_budget(const bpltv_t* h, size_t held) {
+    if (h->opt.adjoint_budget_mb > 0.0) return (size_t)(h->opt.adjoint_budget_mb * 1e6);
     size_t freeb = 0, totalb = 0;
     (void)hipMemGetInfo(&freeb, &totalb);
     const size_t reserve = 2ull << 30;
@@ -935,7 +979,7 @@ size_t adj_budget(size_t held) {
 }
 // images per group so that `per_image` bytes each fit the budget: all O when they fit, at least one
 int adj_group(bpltv_t* h, size_t per_image, size_t held, const char* what, int* Oc) {
-    const size_t budget = adj_budget(held);
+    const size_t budget = adj_budget(h, held);
     size_t g = per_image ? budget / per_image : (size_t)h->O;
     if (g < 1)
         return set_err(h, BPLTV_E_NOMEM, "adjoint gradient (%s): the factor workspace of ONE %dx%d image needs %.2f GB of HBM, %.2f GB available",
@@ -972,7 +1016,7 @@ int bcr_alloc(bpltv_t* h, int* Oc) {
 // Nested-dissection Cholesky (nd_solver.hpp): tree built once per handle, workspace for groups of *Oc images.
 int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, int* Oc, bool lu = false) {
     if (!nd.built) {
-        const int rc = nd.build(h->M, h->N, st, 0, lu);
+        const int rc = nd.build(h->M, h->N, st, h->opt.nd_leaf, lu);
         if (rc) { const std::string m = nd.err; nd.release(); return set_err(h, rc, "adjoint gradient (%s): %s", what, m.c_str()); }
     }
     const size_t per = nd.bytes_per_image();
@@ -995,6 +1039,7 @@ int band_alloc(bpltv_t* h) {
         if (need + (2ull << 30) > freeb)
             return set_err(h, BPLTV_E_NOMEM, "adjoint gradient: the band and its inverted diagonal blocks of %d images of %dx%d need %.1f GB of HBM (%.1f GB free); the nested-dissection factorisation (the default for this shape) needs a fraction of that and runs in image groups",
                            h->O, h->M, h->N, need / 1e9, freeb / 1e9);
+        h->hb.opt_sync = h->opt.hb_sync; h->hb.opt_single_stream = h->opt.hb_single_stream; h->hb.opt_rw = h->opt.hb_rw;
         const int rc = h->hb.alloc(h->M, (int)h->npx, h->O, h->stream);
         if (rc) return set_err(h, rc, "adjoint gradient (HBM band): %s", h->hb.err.c_str());
     }
@@ -1205,18 +1250,24 @@ int run_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, int r
             factor_band_lds(h);
         }
         HIPCHK(h, hipGetLastError());
-        auto solve = [&](double* vec, double* accv) {
+        auto solve = [&](double* vec, double* accv) -> int {
             if (method == ADJ_BCR) bcr_solve_launch(h->stream, bcr, M, N, nimg, h->bcr_MP, vec, accv, band4);
-            else if (method == ADJ_ND) (void)h->nd.solve(vec, accv, nimg);
+            else if (method == ADJ_ND) {
+                const int r2 = h->nd.solve(vec, accv, nimg);
+                if (r2) return set_err(h, r2, "adjoint gradient (nested dissection, substitution): %s", h->nd.err.c_str());
+            }
             else if (method == ADJ_BAND_HBM) solve_band_hbm(h, vec, accv);
             else solve_band_lds(h, vec, accv);
+            return BPLTV_OK;
         };
         // solve + iterative refinement against the matrix-free operator
         HIPCHK(h, hipMemcpyAsync(dp, C.rhs, ctot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        solve(dp, nullptr);
+        rc = solve(dp, nullptr);
+        if (rc) return rc;
         for (int it = 0; it < nref; ++it) {
             hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, dr);
-            solve(dr, dp);
+            rc = solve(dr, dp);
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, dr);
         double* resn_part = h->d_resn + 4 * (size_t)O + 4 * (size_t)c0 * RESN_BLK;
@@ -1562,31 +1613,8 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
             if (exs.size() == 1) {
                 HIPCHK(h, hipGraphLaunch(exs[0], h->stream));
             } else {
-                if (h->chain_streams.empty()) {
-                    hipStream_t cs = nullptr;
-                    hipEvent_t ce = nullptr;
-                    HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-                    HIPCHK(h, hipEventCreateWithFlags(&ce, hipEventDisableTiming));
-                    h->chain_streams.push_back(cs);
-                    h->chain_events.push_back(ce);
-                }
-                hipError_t e1 = hipSuccess;
-                auto launch1 = [&]() {
-                    e1 = hipSetDevice(h->device);
-                    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(h->chain_streams[0], h->ev[0], 0);
-                    if (e1 == hipSuccess) e1 = hipGraphLaunch(exs[1], h->chain_streams[0]);
-                    if (e1 == hipSuccess) e1 = hipEventRecord(h->chain_events[0], h->chain_streams[0]);
-                };
-                std::thread th;
-                bool threaded = nl >= 128;   // short sequences: a helper thread costs more than it hides
-                if (threaded) {
-                    try { th = std::thread(launch1); } catch (...) { threaded = false; }
-                }
-                const hipError_t e0 = hipGraphLaunch(exs[0], h->stream);
-                if (threaded) th.join(); else launch1();
-                HIPCHK(h, e0);
-                HIPCHK(h, e1);
-                HIPCHK(h, hipStreamWaitEvent(h->stream, h->chain_events[0], 0));
+                rc = launch_chains(h, exs, nl >= 128);   // short sequences: a helper thread costs more than it hides
+                if (rc) return rc;
             }
             h->st.graph_used = 1;
             done = true;
@@ -1632,6 +1660,7 @@ int sr_band_alloc(bpltv_t* h) {
     const size_t need = h->hb_sr.bytes_needed(bw, n, h->O);
     if (need + (2ull << 30) > freeb)
         return set_err(h, BPLTV_E_NOMEM, "sum-of-regularisers adjoint (HBM band): %.1f GB of HBM needed, %.1f GB free", need / 1e9, freeb / 1e9);
+    h->hb_sr.opt_sync = h->opt.hb_sync; h->hb_sr.opt_single_stream = h->opt.hb_single_stream; h->hb_sr.opt_rw = h->opt.hb_rw;
     const int rc = h->hb_sr.alloc(bw, n, h->O, h->stream);
     if (rc) return set_err(h, rc, "sum-of-regularisers adjoint (HBM band): %s", h->hb_sr.err.c_str());
     h->sr_band_ready = true;
@@ -1650,9 +1679,8 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
     const int M = h->M, N = h->N, O = h->O, am = h->last_am, an = h->last_an;
     const size_t tot = h->tot, P = (size_t)am * an, npx = h->npx;
     const int patch = !(am == 1 && an == 1);
-    const char* force_lu = getenv("BPLTV_SR_FORCE_LU");   // test aid: the LU path on the symmetric systems too
     const bool rowsc = reg && patch;
-    const bool lu = rowsc || (force_lu && force_lu[0] == '1');
+    const bool lu = rowsc || h->opt.sr_force_lu == 1;   // option "sr_force_lu": test aid, the LU path on the symmetric systems too
     if (p.reserved[4] == 2) return set_err(h, BPLTV_E_UNSUPPORTED, "block cyclic reduction applies to the TV model only");
     const bool band = p.reserved[4] == 1;     // the band solvers (Cholesky / LU) instead of nested dissection
     int Oc = O;
@@ -1730,17 +1758,21 @@ int run_sr_gradient_once(bpltv_t* h, const double* d_u, const double* d_ubar, in
             hipLaunchKernelGGL(sr_adj_flux_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, M, N, nimg, w);
             hipLaunchKernelGGL(sr_adj_residual_kernel, dim3(gpx), dim3(256), 0, h->stream, C, dp, w, M, N, nimg, out, rowscale, am, an);
         };
-        auto solve = [&](double* v, double* acc) {
-            if (lu && !band) (void)h->nd_sr_lu.solve(v, acc, nimg);
+        auto solve = [&](double* v, double* acc) -> int {
+            int r2 = 0;
+            if (lu && !band) { if ((r2 = h->nd_sr_lu.solve(v, acc, nimg))) return set_err(h, r2, "sum-of-regularisers adjoint (nested dissection, LU, substitution): %s", h->nd_sr_lu.err.c_str()); }
             else if (lu) h->lu_sr.solve(v, acc, h->d_gpix);
             else if (band) h->hb_sr.solve(v, acc, h->d_gpix);
-            else (void)h->nd_sr.solve(v, acc, nimg);
+            else if ((r2 = h->nd_sr.solve(v, acc, nimg))) return set_err(h, r2, "sum-of-regularisers adjoint (nested dissection, substitution): %s", h->nd_sr.err.c_str());
+            return BPLTV_OK;
         };
         HIPCHK(h, hipMemcpyAsync(dp, C.rhs, ctot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        solve(dp, nullptr);
+        rc = solve(dp, nullptr);
+        if (rc) return rc;
         for (int it = 0; it < nref; ++it) {
             residual(dr);
-            solve(dr, dp);
+            rc = solve(dr, dp);
+            if (rc) return rc;
         }
         residual(dr);
         double* resn_part = h->d_resn + 4 * (size_t)O + 4 * (size_t)c0 * RESN_BLK;
@@ -2207,6 +2239,7 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
+    HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     HIPCHK(h, hipMalloc((void**)&h->d_ubar, h->tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_f, h->tot * sizeof(double)));
     for (int s = 0; s < 2; ++s)
@@ -2251,7 +2284,9 @@ int bpltv_destroy(bpltv_t* h) {
     }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->launcher.reset();   // joins the launcher thread (idle: every call waits for its job)
     drop_graphs(h);
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     for (auto cs : h->chain_streams) (void)hipStreamDestroy(cs);
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
@@ -2630,6 +2665,45 @@ int bpltv_per_image(bpltv_t* h, double* out) {
     for (int k = 0; k < O; ++k) {
         out[(size_t)k * (1 + P)] = cost[k];
         for (int q = 0; q < P; ++q) out[(size_t)k * (1 + P) + 1 + q] = g[(size_t)q * O + k];
+    }
+    return BPLTV_OK;
+}
+
+int bpltv_set_option(bpltv_t* h, const char* name, double value) {
+    if (!h) return BPLTV_E_ARG;
+    if (!name || !std::isfinite(value)) return set_err(h, BPLTV_E_ARG, "set_option: null name or non-finite value");
+    if (h->multi) {
+        const std::string nm(name);
+        return multi_run(h, [&](int, bpltv_t* c) { return bpltv_set_option(c, nm.c_str(), value); });
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const std::string nm(name);
+    const int iv = (int)value;
+    if (nm == "adjoint_budget_mb") {
+        if (value < 0.0) return set_err(h, BPLTV_E_ARG, "set_option(adjoint_budget_mb): must be >= 0");
+        h->opt.adjoint_budget_mb = value;
+    } else if (nm == "sr_force_lu") {
+        h->opt.sr_force_lu = iv ? 1 : 0;
+    } else if (nm == "nd_leaf") {
+        if (iv < 0 || iv > 4096) return set_err(h, BPLTV_E_ARG, "set_option(nd_leaf): 0 (default) or 1..4096 pixels");
+        if (iv != h->opt.nd_leaf) {   // the trees are built for a leaf size: drop them
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->nd.release(); h->nd_sr.release(); h->nd_sr_lu.release();
+        }
+        h->opt.nd_leaf = iv;
+    } else if (nm == "hb_sync" || nm == "hb_single_stream" || nm == "hb_rw") {
+        if (nm == "hb_sync" && (iv < 0 || iv > 2)) return set_err(h, BPLTV_E_ARG, "set_option(hb_sync): 0 automatic, 1 events, 2 stream memory operations");
+        if (nm == "hb_rw" && iv != 0 && iv != 32 && iv != 128) return set_err(h, BPLTV_E_ARG, "set_option(hb_rw): 0, 32 or 128");
+        int& f = nm == "hb_sync" ? h->opt.hb_sync : (nm == "hb_single_stream" ? h->opt.hb_single_stream : h->opt.hb_rw);
+        const int nv = nm == "hb_single_stream" ? (iv ? 1 : 0) : iv;
+        if (nv != f) {   // the band solvers read these when their workspace is made: drop the workspaces
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->band_ready && h->adj_hbm) { h->hb.release(); h->band_ready = false; }
+            if (h->sr_band_ready) { h->hb_sr.release(); h->sr_band_ready = false; }
+        }
+        f = nv;
+    } else {
+        return set_err(h, BPLTV_E_ARG, "set_option: unknown option '%s'", name);
     }
     return BPLTV_OK;
 }

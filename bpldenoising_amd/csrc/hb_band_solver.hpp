@@ -56,8 +56,19 @@ struct HbBandSolver {
     bool value_sync = false, sync_err = false;
     unsigned* sig[4] = {nullptr, nullptr, nullptr, nullptr};   // counters in signal memory (value_sync)
     unsigned seq[4] = {0, 0, 0, 0};
-    int rw_force = 0;            // BPLTV_HB_RW = 32 | 128: rows per tile workgroup of the substitutions (0: by size)
-    bool single_stream = false;  // profiling aid (BPLTV_HB_SINGLE_STREAM=1): rocprofv3 --pmc cannot follow two streams
+    int rw_force = 0;            // 32 | 128: rows per tile workgroup of the substitutions (0: by size)
+    bool single_stream = false;  // profiling aid: rocprofv3 --pmc cannot follow two streams
+    // set before alloc() by the owner (bpltv_set_option "hb_sync" / "hb_single_stream" / "hb_rw"; the unit tools read
+    // their own environment): 0 = automatic
+    int opt_sync = 0, opt_single_stream = 0, opt_rw = 0;
+    void options_from_env() {   // tools/ only (lu_unit, nd_unit): BPLTV_HB_SYNC=event|value, BPLTV_HB_SINGLE_STREAM=1, BPLTV_HB_RW
+        const char* e4 = getenv("BPLTV_HB_SYNC");
+        opt_sync = e4 ? (e4[0] == 'e' ? 1 : (e4[0] == 'v' ? 2 : 0)) : 0;
+        const char* e1 = getenv("BPLTV_HB_SINGLE_STREAM");
+        opt_single_stream = (e1 && e1[0] == '1') ? 1 : 0;
+        const char* e6 = getenv("BPLTV_HB_RW");
+        opt_rw = e6 ? atoi(e6) : 0;
+    }
     std::string err;
 
     struct Bufs {
@@ -122,18 +133,14 @@ struct HbBandSolver {
         Shape s = allow_twist ? shape(bw, n) : Shape{1, 0, 0, n_};
         twisted = s.sides == 2; sides = s.sides; m = s.m; nm = s.nm; np = s.np;
         const size_t W = (size_t)bw + 1;
-        const char* e1 = getenv("BPLTV_HB_SINGLE_STREAM");
-        single_stream = e1 && e1[0] == '1';
-        const char* e6 = getenv("BPLTV_HB_RW");
-        rw_force = e6 ? atoi(e6) : 0;
-        if (rw_force != 32 && rw_force != 128) rw_force = 0;
-        {   // cross-stream dependencies by stream memory operations where the device has them (BPLTV_HB_SYNC=event:
-            // HIP events instead; rocprofv3 needs that -- it stalls every stream memory operation)
-            const char* e4 = getenv("BPLTV_HB_SYNC");
+        single_stream = opt_single_stream != 0;
+        rw_force = (opt_rw == 32 || opt_rw == 128) ? opt_rw : 0;
+        {   // cross-stream dependencies by stream memory operations where the device has them (opt_sync = 1: HIP events
+            // instead; rocprofv3 needs that -- it stalls every stream memory operation)
             int dev = 0, can = 0;
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) can = 0;
-            value_sync = can != 0 && !(e4 && e4[0] == 'e');
+            value_sync = can != 0 && opt_sync != 1;
             if (value_sync)
                 for (auto& q : sig) {
                     if (hipExtMallocWithFlags((void**)&q, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(q, 0, 8) != hipSuccess) {
@@ -142,8 +149,8 @@ struct HbBandSolver {
                         break;
                     }
                 }
-            if (e4 && e4[0] == 'v' && !value_sync) {   // asked for explicitly: no silent fallback to events
-                err = "BPLTV_HB_SYNC=value: stream memory operations (hipStreamWaitValue32 on signal memory) are not available on this device";
+            if (opt_sync == 2 && !value_sync) {   // asked for explicitly: no silent fallback to events
+                err = "hb_sync = value: stream memory operations (hipStreamWaitValue32 on signal memory) are not available on this device";
                 return 2;
             }
         }

@@ -18,6 +18,11 @@
 
 namespace bpltv {
 
+// dynamic LDS of the split substitution kernels (nd_fwd_rows_kernel: pivot vector + 8 partial rows of 128; nd_bwd_cols_kernel:
+// boundary vector + a reduction line)
+inline size_t nd_rows_lds(int pmax) { return sizeof(double) * ((size_t)pmax + 8 * HB2_NB); }
+inline size_t nd_cols_lds(int bmax) { return sizeof(double) * ((size_t)bmax + 64); }
+
 struct NdSolver {
     NdTree T;
     struct Level {
@@ -49,12 +54,6 @@ struct NdSolver {
         }                                                                                         \
     } while (0)
 
-    static int default_leaf() {
-        const char* e = getenv("BPLTV_ND_LEAF");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 32;
-    }
-
     // bytes of device memory per image of the workspace (factor, two update-matrix workspaces, vectors)
     size_t bytes_per_image() const {
         return sizeof(double) * (size_t)((lu ? 2 : 1) * (T.fac_doubles + T.ws_doubles[0] + T.ws_doubles[1]) + T.uv_doubles + T.n);
@@ -68,7 +67,8 @@ struct NdSolver {
     int build(int M, int N, const NdStencil& st, int leaf_pix = 0, bool lu_variant = false) {
         release();
         lu = lu_variant;
-        T = nd_build(M, N, st, leaf_pix > 0 ? leaf_pix : default_leaf());
+        T = nd_build(M, N, st, leaf_pix > 0 ? leaf_pix : 32);
+        if (!T.ok) { err = "nested dissection, symbolic phase: " + T.err; return 6; }
         factor_flop = 2.0 * T.flops();
         const int L = T.levels();
         lv.assign(L, Level());
@@ -133,6 +133,14 @@ struct NdSolver {
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_getri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)nd_getri_lds()));
         if (nd_large_lds(T.max_f) > 160 * 1024) { err = "front too large for the substitution kernels"; return 6; }
+        {   // the split substitutions of fronts with many boundary rows stage a pivot / boundary vector in dynamic LDS
+            int bmax_all = 0;
+            for (const NdNode& v : T.nodes) bmax_all = std::max(bmax_all, v.b);
+            const size_t rows_lds = nd_rows_lds(T.max_p), cols_lds = nd_cols_lds(bmax_all);
+            if (rows_lds > 160 * 1024 || cols_lds > 160 * 1024) { err = "pivot block or boundary too long for the split substitution kernels"; return 6; }
+            NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_fwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+            NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_bwd_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cols_lds));
+        }
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_fwd_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)nd_large_lds(T.max_f)));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_bwd_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -301,7 +309,7 @@ struct NdSolver {
                     hipLaunchKernelGGL(nd_fwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S, split);
                     if (split)
                         hipLaunchKernelGGL(nd_fwd_rows_kernel, dim3((a.bmax + HB2_NB - 1) / HB2_NB, qn, nimg), dim3(NDL_T),
-                                           sizeof(double) * ((size_t)a.pmax + 8 * HB2_NB), stream, S);
+                                           nd_rows_lds(a.pmax), stream, S);
                 }
             }
         }
@@ -316,7 +324,7 @@ struct NdSolver {
                     const int split = a.bmax >= 256 ? 1 : 0;
                     if (split)
                         hipLaunchKernelGGL(nd_bwd_cols_kernel, dim3((a.pmax + HB2_NB - 1) / HB2_NB, qn, nimg), dim3(NDL_T),
-                                           sizeof(double) * ((size_t)a.bmax + 64), stream, S);
+                                           nd_cols_lds(a.bmax), stream, S);
                     hipLaunchKernelGGL(nd_bwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S, split);
                 }
             }

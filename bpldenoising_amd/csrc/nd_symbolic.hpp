@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace bpltv {
@@ -76,6 +77,8 @@ struct NdTree {
     int64_t ws_doubles[2] = {0, 0};       // update-matrix workspace per image for even / odd levels
     int64_t uv_doubles = 0;               // update vectors per image
     int max_f = 0, max_p = 0;
+    bool ok = true;                       // false: an invariant of the construction failed (err says which); the tree is unusable
+    std::string err;
     int levels() const { return (int)lvl_start.size() - 1; }
     double flops() const {                // of one factorisation (multiply-adds counted as 2)
         double s = 0;
@@ -210,7 +213,10 @@ inline NdTree nd_build(int M, int N, const NdStencil& st, int leaf_pix = 32) {
                     const int g2 = a + M * c;
                     if (T.elim[g2] < T.elim[g]) continue;           // assembled where g2 was a pivot (or it is k' < k here)
                     const int k2 = pos[g2];                          // in this front by construction
-                    if (k2 < 0 || k2 >= f || T.pix[v.piv_off + k2] != g2) abort();
+                    if (k2 < 0 || k2 >= f || T.pix[v.piv_off + k2] != g2) {
+                        T.ok = false; T.err = "matrix entry of front " + std::to_string(q) + " couples a pixel outside the front";
+                        return T;
+                    }
                     // plane s stores A[c + off][c] at the pixel of smaller linear index
                     T.orig.push_back({k2, k, sg > 0 ? s : (s | ND_ORIG_UPPER), sg > 0 ? g : g2});
                 }
@@ -223,7 +229,10 @@ inline NdTree nd_build(int M, int N, const NdStencil& st, int leaf_pix = 32) {
             for (int k = 0; k < ch.b; ++k) {
                 const int g = T.pix[ch.piv_off + ch.p + k];
                 const int k2 = pos[g];
-                if (k2 < 0 || k2 >= f || T.pix[v.piv_off + k2] != g) abort();   // the child's boundary lies in the parent's front
+                if (k2 < 0 || k2 >= f || T.pix[v.piv_off + k2] != g) {   // the child's boundary lies in the parent's front
+                    T.ok = false; T.err = "boundary of front " + std::to_string(v.child[ci]) + " is not contained in its parent's front";
+                    return T;
+                }
                 T.cmap.push_back(k2);
             }
         }

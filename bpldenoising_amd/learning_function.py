@@ -272,6 +272,10 @@ class TVSolver:
         self._check(self._lib.bpltv_grad_fwd_adjoint(self._h, _ptr(y1), _ptr(y2), _ptr(out)))
         return out
 
+    def set_option(self, name, value):
+        """bpltv_set_option: test / measurement aids (include/bpltv.h), e.g. set_option("adjoint_budget_mb", 40)."""
+        self._check(self._lib.bpltv_set_option(self._h, name.encode(), float(value)))
+
     def stats(self):
         s = _lib.BpltvStats()
         self._check(self._lib.bpltv_stats(self._h, C.byref(s)))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BPLTV_VERSION 3
+#define BPLTV_VERSION 4
 
 enum {
     BPLTV_OK = 0,
@@ -49,7 +49,7 @@ enum {
 /* Sizes: PDHG, loss, sweep and the adjoint gradient accept any M x N x O whose images fit in HBM.  The gradient
  * factors its linear system by a nested-dissection (multifrontal) Cholesky (about 0.9 KB of workspace per pixel:
  * 0.94 GB for a 1024 x 1024 image); when the workspace of all O images does not fit it runs in groups of as many
- * images as fit, with bitwise the same result (stats.adjoint_chunks; BPLTV_ADJ_BUDGET_MB forces a budget).
+ * images as fit, with bitwise the same result (stats.adjoint_chunks; bpltv_set_option "adjoint_budget_mb" forces a budget).
  * params.reserved[4] selects the cross-check solvers: banded Cholesky (LDS window for M <= 138, HBM-resident band
  * of M*N*(M+1) doubles per image beyond; whole batch at once) or block cyclic reduction (M <= 128).  All workspaces
  * are allocated on first use and released again if an allocation fails. */
@@ -141,7 +141,7 @@ typedef struct bpltv_stats {
     int hb_sync;               /* cross-stream dependencies of the HBM band pipeline used by the last gradient:
                                   0 not used, 1 HIP events, 2 stream memory operations (hipStreamWaitValue32)    */
     int adjoint_chunks;        /* image groups the last adjoint gradient was processed in (1 = whole batch at once;
-                                  more when the factor workspace of all images does not fit, BPLTV_ADJ_BUDGET_MB) */
+                                  more when the factor workspace of all images does not fit, option "adjoint_budget_mb") */
     int pdhg_variant;          /* 1-based index of the PDHG kernel the last solve ran (the variant table of
                                   csrc/bpltv.hip: 1..15 pdhg_tile_kernel, 16..18 pdhg_wave_kernel, 19.. pdhg_rows_kernel;
                                   sum of regularisers: 1 sr_tile_kernel, 2 sr_strip_kernel)                      */
@@ -256,6 +256,21 @@ int bpltv_gradient(bpltv_t *h, const double *u, const double *ubar, const double
  * or K*M*N*O doubles (parameter-major).  Use maxiter = 10000 for the TVDenoise setting. */
 int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const bpltv_params *p,
                 double *cost_out, double *u_out);
+
+/* Handle options: aids for tests and measurements, none of them changes a result or is needed for the reference's
+ * behaviour (the reference has no counterpart; its sparse `\` at src/TVLearningFunctionVec.jl:131,248 has no knobs).
+ * They replace the environment variables earlier versions read on the product path.  Unknown names: BPLTV_E_ARG.
+ *   "adjoint_budget_mb"  > 0: HBM (MB) the adjoint's factor workspace may take -- forces the gradient to run in image
+ *                        groups (stats.adjoint_chunks; bitwise the same result); 0 = what is free minus a 2 GB reserve
+ *   "sr_force_lu"        1: sum of regularisers -- factor the symmetric systems by the LU variant of the nested
+ *                        dissection as well (cross-check of that variant)
+ *   "nd_leaf"            leaf size in pixels of the nested-dissection tree (0 = 32)
+ *   "hb_sync"            HBM band cross-check solver (params.reserved[4] = 1): 0 automatic, 1 HIP events (what a
+ *                        rocprofv3 run needs), 2 stream memory operations (BPLTV_E_HIP when the device has none)
+ *   "hb_single_stream"   1: that solver's three streams folded into one (rocprofv3 --pmc)
+ *   "hb_rw"              32 | 128: rows per workgroup of its substitutions (0 = by size)
+ * Multi-device handles pass the option to every shard. */
+int bpltv_set_option(bpltv_t *h, const char *name, double value);
 
 int bpltv_stats(bpltv_t *h, bpltv_stats_t *out);
 const char *bpltv_last_error(bpltv_t *h);

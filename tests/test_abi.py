@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libbpltv.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names          # the binding covers exactly the header
-    assert lib.bpltv_version() == 3
+    assert lib.bpltv_version() == 4
 
 
 def test_default_params_match_reference():

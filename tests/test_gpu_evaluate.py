@@ -528,21 +528,21 @@ def test_larger_batches_of_small_images_same_bits_whatever_the_plan(gpu_solver_c
 
 def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
     """The three-stream factorisation resolves its cross-stream dependencies by stream memory operations (default) or
-    by HIP events (BPLTV_HB_SYNC=event, what rocprofv3 runs need): same kernels in the same order, so the gradients
+    by HIP events (bpltv_set_option "hb_sync" = 1, what rocprofv3 runs need): same kernels in the same order, so the gradients
     are bitwise equal -- a missing dependency in either would show here (twisted, 3 images, 6 half-problems)."""
     O, N, M = 3, 48, 300
     ub, f = synth_batch(O, N, M, seed=77)
     amap = 0.05 + 0.1 * np.random.default_rng(9).random((N, M))
     res = []
     for mode in ("value", "event", "single-stream"):   # the last: everything on one stream (the profiling aid)
-        monkeypatch.setenv("BPLTV_HB_SYNC", "event" if mode == "single-stream" else mode)
-        monkeypatch.setenv("BPLTV_HB_SINGLE_STREAM", "1" if mode == "single-stream" else "0")
         s = gpu_solver_cls(M, N, O)
+        s.set_option("hb_sync", 2 if mode == "value" else 1)
+        s.set_option("hb_single_stream", 1 if mode == "single-stream" else 0)
         s.set_data(ub, f)
         _, _, g = s.evaluate(amap, 0.1, maxiter=300, adjoint_method="band")
         st = s.stats()
         assert st["adjoint_method"] == "band-hbm" and st["adjoint_residual"] <= 1e-8
-        # the mode that ran, as the library reports it: BPLTV_HB_SYNC=value fails hard when stream memory operations
+        # the mode that ran, as the library reports it: hb_sync = 2 (value) fails hard when stream memory operations
         # are unavailable, so the 'value' leg cannot pass as a second 'event' leg
         assert st["hb_sync"] == ("value" if mode == "value" else "event"), st["hb_sync"]
         res.append(g)
@@ -570,13 +570,12 @@ def test_nd_solver_unit_checks(gpu_solver_cls):
 def test_adjoint_in_image_groups_is_bitwise_the_whole_batch(gpu_solver_cls, monkeypatch, shape, alpha, method, budget_mb):
     """When the factor workspace of all images does not fit in HBM the gradient runs in image groups (the
     reference's loop is sequential and has no such limit, /root/reference/src/TVLearningFunctionVec.jl:76-81).
-    BPLTV_ADJ_BUDGET_MB forces that on a small case: cost and gradient are BITWISE those of the whole batch at once
+    bpltv_set_option "adjoint_budget_mb" forces that on a small case: cost and gradient are BITWISE those of the whole batch at once
     (per-image results do not depend on the other images of a launch; sums run per image, in image order)."""
     O, N, M = shape
     ub, f = synth_batch(O, N, M, seed=5 + M)
     if isinstance(alpha, str):
         alpha = 0.05 + 0.1 * np.random.default_rng(8).random((N, M))
-    monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB", raising=False)
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
     u0, c0, g0 = s.evaluate(alpha, 0.1, maxiter=300, adjoint_method=method)
@@ -587,8 +586,8 @@ def test_adjoint_in_image_groups_is_bitwise_the_whole_batch(gpu_solver_cls, monk
     if budget_mb is None:       # two images' worth of this shape's nested-dissection workspace
         import ctypes as C
         budget_mb = 2.5 * _nd_bytes_per_image(M, N) / 1e6
-    monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "%.3f" % budget_mb)
     s = gpu_solver_cls(M, N, O)
+    s.set_option("adjoint_budget_mb", budget_mb)
     s.set_data(ub, f)
     u1, c1, g1 = s.evaluate(alpha, 0.1, maxiter=300, adjoint_method=method)
     st1 = s.stats()
@@ -597,16 +596,15 @@ def test_adjoint_in_image_groups_is_bitwise_the_whole_batch(gpu_solver_cls, monk
     if rows0 is not None:
         assert np.array_equal(s.per_image(), rows0)
     _, _, r1 = s.evaluate(alpha, 0.0, maxiter=300, adjoint_method=method)       # gradient_reg in groups too
-    monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB")
     s.close()
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
     _, _, r0 = s.evaluate(alpha, 0.0, maxiter=300, adjoint_method=method)
     assert np.array_equal(np.asarray(r1), np.asarray(r0))
     # a budget below one image's workspace is an error that says so, not a crash
-    monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "0.001")
     from bpldenoising_amd._lib import BpltvError
     s2 = gpu_solver_cls(M, N, O)
+    s2.set_option("adjoint_budget_mb", 0.001)
     s2.set_data(ub, f)
     with pytest.raises(BpltvError) as e:
         s2.evaluate(alpha, 0.1, maxiter=10, adjoint_method=method)

@@ -324,6 +324,24 @@ def test_run_time_choices_and_gap_checks_on_a_large_image(gpu_solver_cls, oracle
     s.close()
 
 
+def test_prepared_start_with_two_threaded_launch_chains_1024(gpu_solver_cls, oracle):
+    """A prepared start (params.init / order) on a batch that runs as TWO launch chains with >= 128 launches each, so that
+    chain 1 is launched from the handle's launcher thread while pdhg_init_kernel may still be running on the handle's
+    stream: the chains fork behind the init kernel (fork event), not behind the timing event in front of it.
+    2 x 1024^2, pixel map, 1040 iterations = 130 launches at T = 8; chain 1 owns the image the init kernel writes last."""
+    O, N, M = 2, 1024, 1024
+    ub, f = synth_batch(O, N, M, seed=31)
+    jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+    alpha = 0.11 + 0.09 * np.sin(2 * np.pi * ii / M) * np.cos(2 * np.pi * jj / N)
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u = s.denoise(alpha, maxiter=1040, init=1, order=1, chains=2)
+    st = s.stats()
+    assert st["graph_used"] == 1 and st["launches"] >= 2 * 128, st
+    assert np.array_equal(u, oracle.pdhg_opts(f, alpha, maxiter=1040, init=1, order=1))
+    s.close()
+
+
 def test_run_time_choices_are_rejected_where_unsupported(gpu_solver_cls):
     from bpldenoising_amd._lib import BpltvError
     ub, f = synth_batch(1, 32, 32, seed=2)

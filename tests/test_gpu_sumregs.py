@@ -143,7 +143,7 @@ def test_drivers_hip_vs_oracle(gpu_solver_cls, oracle, tmp_path):
 
 
 def test_gradients_in_image_groups_are_bitwise_the_whole_batch(gpu_solver_cls, monkeypatch):
-    """The sum-of-regularisers gradients under a forced workspace budget (BPLTV_ADJ_BUDGET_MB): nested-dissection Cholesky
+    """The sum-of-regularisers gradients under a forced workspace budget (bpltv_set_option "adjoint_budget_mb"): nested-dissection Cholesky
     and its LU variant (patch parameter, Delta <= Delta_t) run in image groups and return bitwise the whole-batch result."""
     import os, re, subprocess
     from conftest import ROOT
@@ -153,11 +153,9 @@ def test_gradients_in_image_groups_are_bitwise_the_whole_batch(gpu_solver_cls, m
     per_image = float(re.search(r"bytes_per_image sr (\d+)", out).group(1))
     res = {}
     for budget in (None, 2.5 * per_image / 1e6):
-        if budget is None:
-            monkeypatch.delenv("BPLTV_ADJ_BUDGET_MB", raising=False)
-        else:
-            monkeypatch.setenv("BPLTV_ADJ_BUDGET_MB", "%.4f" % budget)
         s = gpu_solver_cls(M, N, O)
+        if budget is not None:
+            s.set_option("adjoint_budget_mb", budget)
         s.set_data(ub, f)
         _, c, g = s.sumregs_evaluate(P3, 0.1, maxiter=300)
         ch = s.stats()["adjoint_chunks"]

@@ -34,10 +34,9 @@ for case in range(cases):
     reg = bool(rng.integers(0, 2))
     ub, f = synth_batch(O, N, M, seed=int(rng.integers(1, 10000)))
     meth = str(rng.choice(["auto", "auto", "band", "bcr" if (M <= 128 and N >= 2) else "nd"]))
-    os.environ.pop("BPLTV_ADJ_BUDGET_MB", None)
-    if meth in ("auto", "nd") and O > 1 and rng.random() < 0.3:
-        os.environ["BPLTV_ADJ_BUDGET_MB"] = "%.3f" % (1.3 * 8e-6 * 40 * M * N * max(4, np.log2(M * N)))   # a group of about one image
     s = TVSolver(M, N, O); s.set_data(ub, f)
+    if meth in ("auto", "nd") and O > 1 and rng.random() < 0.3:
+        s.set_option("adjoint_budget_mb", 1.3 * 8e-6 * 40 * M * N * max(4, np.log2(M * N)))   # a group of about one image
     try:
         u, c, g = s.evaluate(alpha, 0.0 if reg else 0.1, maxiter=300, adjoint_method=meth)
         st = s.stats()

@@ -74,6 +74,7 @@ static bool run_case(int n, int bw, const std::vector<int>& offs, bool sym, int 
         if (!rc) rc = lu.factor(DL, DU, d_fail);
         if (!rc) lu.solve(d_v, nullptr, d_s);
     } else {
+        ch.options_from_env();
         rc = ch.alloc(bw, n, O, st);
         if (!rc) rc = ch.factor(DL, d_fail);
         if (!rc) ch.solve(d_v, nullptr, d_s);
