@@ -16,8 +16,9 @@ never as `value`; `--scaling weak` makes it the timed workload.  `--multi-handle
 single-process form instead: ONE bpltv_create_multi handle over N devices (worker thread per device
 and the RCCL collective inside the library) -- the form INTEGRATION.md gives the Julia caller.
 
-Rank 0 prints one JSON line with `roofline` (dominant kernel pdhg_tile_kernel, HBM-bound
-accounting: 56 B per pixel per iteration) and `cpu_baseline` (the oracle's C restatement timed on
+Rank 0 prints one JSON line with `roofline` (dominant kernel pdhg_tile_kernel: the binding bound --
+f64 VALU issue or measured HBM traffic, whichever fraction is larger, <= 1 -- with the contractual 56 B per
+pixel-iteration figure aside as `contractual_hbm_frac`) and `cpu_baseline` (the oracle's C restatement timed on
 the host cores: kind "port" -- the reference is Julia and cannot run here).
 """
 import argparse
@@ -147,7 +148,9 @@ def cpu_baseline(args, f_full, ub_full, alpha, N, M):
         "sample": "%d iterations of the full batch, oracle/bpltv_oracle.c (%s), 1 thread (stock Julia runs the reference serially)" % (it1, how1),
         "all_cores": {"value": best[0], "cores": best[1], "how": best[2], "iterations": best[3],
                       "tried": [{"it_per_s": round(v, 1), "threads": n, "how": h, "iterations": k} for v, n, h, k in cands]},
-        "host_cpus_visible": ncpu, "host_cpus_total": os.cpu_count(), "cpu_model": cpu_model(), "compiler_flags": flags,
+        "host_cpus_visible": ncpu, "host_cpus_total": os.cpu_count(), "cpu_model": cpu_model(),
+        "compiler_flags": how1,                  # the build that produced `value` (1 thread)
+        "compiler_flags_all_cores": flags,       # the build of the `all_cores` legs
         "adjoint_s_per_image": cpu_adj,   # the oracle's banded Cholesky + 3 refinement sweeps, one image, 1 thread
     }
 
@@ -177,25 +180,6 @@ def make_alpha(args, N, M):
     return args.alpha
 
 
-def binding_bound(launch_us, valu, hbm_frac_measured, redundancy):
-    """What actually bounds the kernel: the contractual HBM fraction of a temporally blocked
-    kernel is a figure of merit, not a bound.  Candidates: f64 VALU issue (counter-derived floor), HBM traffic as
-    measured, launch latency (what is left when neither explains the launch).  `frac_useful` divides by the
-    halo-recompute redundancy: the share of the launch spent on arithmetic the recurrence itself needs."""
-    cands = []
-    if valu:
-        cands.append(("valu_f64_issue", valu["frac"]))
-    if hbm_frac_measured is not None:
-        cands.append(("hbm", hbm_frac_measured))
-    if not cands:
-        return None
-    name, frac = max(cands, key=lambda c: c[1])
-    if frac < 0.5:
-        name = "launch_latency"   # neither issue nor bandwidth explains half of the launch: fixed launch + barrier latency
-    return {"bound": name, "frac": frac, "frac_useful": frac / redundancy if redundancy else None,
-            "candidates": {k: v for k, v in cands}}
-
-
 def tile_count_py(L, R, T):
     """tile_count of csrc/pdhg_kernels.hpp: regions of R pixels with halo T covering L pixels (image borders need no halo)."""
     if L <= R:
@@ -216,20 +200,32 @@ def kernel_name(st):
     return "pdhg_rows_kernel" if v >= 19 else ("pdhg_wave_kernel" if v >= 16 else "pdhg_tile_kernel")
 
 
+CLOCK_GHZ = 2.4        # /opt/skills/guides/MI355X_MICROARCH.md: max clock 2400 MHz
+F64_ISSUE_CYCLES = 4   # a wave64 f64 VALU instruction occupies its SIMD for 4 cycles (half-rate; v_fma_f64 sustains 59 of the
+                       # nominal 78.6 TFLOP/s in tools/mfma_bench.hip)
+
+
 def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
-    """The `roofline` object for the PDHG kernel (pdhg_tile_kernel; pdhg_rows_kernel on large images) from one solve's statistics."""
+    """The `roofline` object of the PDHG kernel (pdhg_tile_kernel; pdhg_rows_kernel on large images) from one solve's
+    statistics.
+
+    `bound` / `achieved` / `peak` / `frac` are those of the BINDING bound: the candidate (f64 VALU issue, HBM traffic as
+    the counters see it) with the largest fraction -- <= 1 by construction.  The kernel is temporally blocked (state
+    touches HBM once per tile_iters iterations), so the contractual figure of SURVEY 8d -- algorithmic 56 / 64 B per
+    pixel-iteration over the launch time -- is a figure of merit that can exceed the HBM peak; it is reported aside as
+    `contractual_hbm_frac`, with `kernels_in_flight` beside it, never as `frac`.
+    Time base of every fraction: avg_launch_us = HIP-event time of the launch sequence / dispatches (whole-chip time
+    per dispatch; with two launch chains two kernels are in flight and a dispatch holds half the workgroups).
+    Counter figures are NOT measured by this run: they are the committed summaries of separate rocprofv3 --pmc passes of
+    the same command (profiles/traffic.json, written by tools/refresh_profiles.py), scaled to the workgroups of a
+    dispatch and labelled with their source.  VALU floor = SQ_INSTS_VALU x 4 cycles / (CUs x 4 SIMDs) / 2.4 GHz."""
     bytes_px = st["bytes_per_px_iter"]
     bytes_per_launch = bytes_px * M * N * O_local * (iters / max(st["launches"], 1))
-    achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-    # Counter-derived figures are NOT measured by this run: they are the committed summaries of separate
-    # rocprofv3 --pmc passes of the same command (profiles/traffic.json, written by tools/refresh_profiles.py)
-    # and are labelled with their source.
+    contractual = bytes_per_launch / (launch_us * 1e-6) / 1e9
     wl_key = "%dx%dx%d %s" % (O_local, N, M, "map" if bytes_px in (64.0, 32.0) else "scalar")
     traffic, traffic_src, valu_instr = None, None, None
-    # the library runs the batch as `chains` concurrent launch chains (image groups) of tiles / chains workgroups per
-    # dispatch; the counter passes run eager single-chain launches of the whole grid: counters scale with the workgroups
     nl = -(-iters // max(st["tile_iters"], 1))
-    chains = max(1, round(st["launches"] / max(nl, 1)))
+    chains = st.get("launch_chains") or max(1, round(st["launches"] / max(nl, 1)))
     tiles_disp = st["tiles"] / chains
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf) and not f32:   # the committed counters are those of the Float64 kernel
@@ -243,9 +239,6 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
                                                                     "" if scale == 1.0 else ", scaled by %.3g: %d of its %d workgroups per dispatch" % (scale, round(tiles_disp), tj["tiles"]))
         except Exception:
             traffic = None
-    # the temporal blocking trades HBM traffic for redundant halo arithmetic, so beside the contractual HBM figure
-    # the line carries the redundancy and the f64 VALU issue floor: wave-instructions * 4 cycles (a wave64 f64 op
-    # occupies a SIMD for 4 cycles) / (CUs * 4 SIMDs) / 2.4 GHz.
     nit_avg = iters * chains / max(st["launches"], 1)   # iterations per dispatch; a dispatch holds tiles / chains workgroups
     computed_px_it = tiles_disp * st["region_i"] * st["region_j"] * nit_avg
     if kernel_name(st) == "pdhg_rows_kernel":
@@ -258,39 +251,57 @@ def roofline_of(args, st, M, N, O_local, iters, launch_us, kernel_us, f32):
         computed_px_it -= tiles_disp * st["region_i"] * saved_rows * (nit_avg / T_)
     useful_px_it = M * N * O_local / chains * nit_avg
     redundancy = computed_px_it / useful_px_it
-    valu = None
+    ncu = st.get("ncu") or 256
+    valu_peak = ncu * 4 * CLOCK_GHZ * 1e9 / F64_ISSUE_CYCLES / 1e9       # G wave-instructions/s at the f64 rate
+    cands, valu = {}, None
     if valu_instr:
-        floor_us = valu_instr * 4.0 / (256 * 4) / 2.4e3
-        valu = {"bound": "valu_f64_issue", "wave_instructions_per_launch": valu_instr,
-                "instr_per_computed_px_iter": valu_instr * 64.0 / computed_px_it,
-                "floor_us": floor_us, "frac": floor_us / launch_us, "source": traffic_src,
+        rate = valu_instr / (launch_us * 1e-6) / 1e9
+        floor_us = valu_instr * F64_ISSUE_CYCLES / (ncu * 4) / (CLOCK_GHZ * 1e3)
+        cands["valu_f64_issue"] = (rate, valu_peak, "G VALU wave-instructions/s (f64 rate: %d cycles per wave64 instruction)" % F64_ISSUE_CYCLES)
+        valu = {"wave_instructions_per_dispatch": valu_instr, "instr_per_computed_px_iter": valu_instr * 64.0 / computed_px_it,
+                "floor_us": floor_us, "frac": floor_us / launch_us, "cus": ncu, "source": traffic_src,
                 # v_fma_f64 sustains 59 of the nominal 78.6 TFLOP/s on this part (tools/mfma_bench.hip, 8 independent
                 # chains per lane, 1-4 waves per SIMD): against that measured rate the kernel sits this much higher
                 "frac_of_measured_issue_rate": floor_us / launch_us * (78.6 / 59.0),
                 "note": "upper estimate of the issue floor: every VALU instruction priced at the nominal f64 rate (4 cycles at 2.4 GHz)"}
-    measured_hbm_frac = (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None
-    return {"bound": "hbm", "bound_note": "contractual: algorithmic bytes (SURVEY 8d: 56/64 B per pixel-iteration) / launch time; "
-                                          "the fused kernel touches HBM once per tile_iters iterations, see `binding`",
-            "kernel": kernel_name(st), "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "measured_hbm_frac": measured_hbm_frac,   # counter traffic / launch time / peak: the HBM share actually used
-            "binding": binding_bound(launch_us, valu, measured_hbm_frac, redundancy),
+    if traffic:
+        cands["hbm"] = (traffic / (launch_us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s")
+    if cands:
+        bound = max(cands, key=lambda k: cands[k][0] / cands[k][1])
+        achieved, peak, unit = cands[bound]
+        src = traffic_src
+    else:
+        # no counter entry for this plan: the compulsory state traffic (every state word read and written once per
+        # launch, no halo) is what certainly crosses the HBM side -- a lower bound, <= 1 by construction
+        bound, unit, peak = "hbm", "GB/s", HBM_PEAK_GBS
+        achieved = bytes_px * M * N * O_local / chains / (launch_us * 1e-6) / 1e9
+        src = "no counter entry in profiles/traffic.json for this plan: compulsory state traffic per launch (lower bound)"
+    frac = achieved / peak
+    return {"bound": bound, "kernel": kernel_name(st), "achieved": achieved, "peak": peak, "unit": unit, "frac": frac,
+            "frac_useful": frac / redundancy if bound == "valu_f64_issue" else None,   # issue share spent on pixel-iterations the recurrence needs
+            "bound_note": ("the largest of the candidate fractions; what is left of the dispatch time is launch / prologue / barrier "
+                           "latency that neither issue nor bandwidth explains (DESIGN.md 4.1)"),
+            "bound_source": src,
+            "candidates": {k: v[0] / v[1] for k, v in cands.items()},
+            "traffic": traffic, "traffic_source": traffic_src,
+            "measured_hbm_frac": (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "redundancy": redundancy,   # computed / useful pixel-iterations (halo recompute)
             "region": [st["region_i"], st["region_j"]], "valu_f64": valu,
+            # the contractual figure of SURVEY 8d, kept aside: NOT a fraction of a bound for a temporally blocked kernel
+            "contractual_hbm_frac": contractual / HBM_PEAK_GBS, "contractual_hbm_gbs": contractual,
+            "contractual_note": "algorithmic bytes (%g B per pixel-iteration) / dispatch time / 8 TB/s; the fused launch moves those bytes once per %d iterations" % (bytes_px, st["tile_iters"]),
+            "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else chains,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
             "avg_kernel_us_serialized": kernel_us,
-            "kernels_in_flight": max(1, round(kernel_us / launch_us)) if kernel_us else 1,
             "launch_chains": chains,   # concurrent chains of image groups: avg_launch_us = whole time / all dispatches
             "overlap_note": (None if chains == 1 else
                              "%d launch chains run concurrently on two hardware queues: a rocprofv3 kernel trace shows ~%d kernels in flight, "
-                             "each about avg_kernel_us_serialized long (a little longer while overlapped), so dispatches x kernel duration / %d ~ the step time; "
-                             "`achieved` / `frac` use the whole-chip time per dispatch (avg_launch_us), `frac_isolated_kernel` the duration of one kernel alone"
+                             "each about avg_kernel_us_serialized long (a little longer while overlapped), so dispatches x kernel duration / %d ~ the step time"
                              % (chains, chains, chains)),
-            "frac_isolated_kernel": (bytes_per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kernel_us else None,
             "bytes_per_px_iter": bytes_px}
 
 
-def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, evaluate_once, data):
+def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, evaluate_once, data, eval_iters=None):
     """One more workload measured outside the timed region of the default run (N = 1), so that the driver's record
     holds it: the reference's default num_samples = 1 (/root/reference/src/BPLDenoising.jl:313) and the per-GPU
     share of BASELINE config 5.  Inputs resident in HBM; `value` = PDHG iterations/s of that batch."""
@@ -305,19 +316,26 @@ def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, eval
     t_ub, t_f = torch.from_numpy(ub).cuda(), torch.from_numpy(f).cuda()
     torch.cuda.synchronize()
     s.set_data_device(t_ub.data_ptr(), t_f.data_ptr())
-    s.denoise(alpha, fetch=False, maxiter=iters)
+    if alpha_map:   # the parameter map resident in HBM too (8 MiB for 1024^2): no host array in the timed region
+        t_alpha = torch.from_numpy(np.ascontiguousarray(alpha)).cuda()
+        torch.cuda.synchronize()
+        step = lambda: s.denoise_device(t_alpha.data_ptr(), size, size, maxiter=iters)
+    else:
+        step = lambda: s.denoise(alpha, fetch=False, maxiter=iters)
+    step()
     torch.cuda.synchronize()
     ev_ms, ev_l = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(steps):
-        s.denoise(alpha, fetch=False, maxiter=iters)
+        step()
         st = s.stats(); ev_ms += st["pdhg_ms"]; ev_l += st["launches"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     launch_us = 1e3 * ev_ms / max(ev_l, 1)
-    out = {"workload": "%dx%dx%d f64, %s alpha, %d PDHG iterations per step, data %s" % (
-               O, size, size, "per-pixel" if alpha_map else "scalar", iters, label),
+    out = {"workload": "%dx%dx%d f64, %s alpha%s, %d PDHG iterations per step, data %s" % (
+               O, size, size, "per-pixel" if alpha_map else "scalar", " (resident in HBM)" if alpha_map else "", iters, label),
            "value": steps * iters / dt, "unit": "PDHG iterations/s of that batch", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "value_from_events": steps * iters / (1e-3 * ev_ms) if ev_ms else None,   # the same from the HIP events of the launch sequence
            "tile_iters": st["tile_iters"], "tiles_per_launch": st["tiles"],
            "roofline": roofline_of(a, st, size, size, O, iters, launch_us, None, False)}
     if evaluate_once:
@@ -325,12 +343,12 @@ def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, eval
         best = None
         for _ in range(2):   # the first call allocates the adjoint workspace
             t1 = time.perf_counter()
-            s.evaluate_device(alpha, 0.1, part.data_ptr(), maxiter=iters)
+            s.evaluate_device(alpha, 0.1, part.data_ptr(), maxiter=eval_iters or iters)
             torch.cuda.synchronize()
             e_ms = 1e3 * (time.perf_counter() - t1)
             s3 = s.stats()
             if best is None or e_ms < best["evaluate_ms"]:
-                best = {"evaluate_ms": e_ms, "pdhg_ms": s3["pdhg_ms"], "adjoint_ms": s3["adjoint_ms"],
+                best = {"evaluate_ms": e_ms, "pdhg_iterations": eval_iters or iters, "pdhg_ms": s3["pdhg_ms"], "adjoint_ms": s3["adjoint_ms"],
                         "adjoint_method": s3["adjoint_method"], "adjoint_residual": s3["adjoint_residual"],
                         "adjoint_chunks": s3["adjoint_chunks"]}
         out["learning_function"] = best
@@ -625,7 +643,7 @@ def main():
             try:
                 out["extra_workloads"] = {
                     "single_image": extra_workload(TVSolver, torch, "single_image", 1, 128, args.iters, 5, False, True, "faces_train_128_10"),
-                    "config5_share": extra_workload(TVSolver, torch, "config5_share", 8, 1024, 400, 3, True, True, "synthetic"),
+                    "config5_share": extra_workload(TVSolver, torch, "config5_share", 8, 1024, 2000, 3, True, True, "synthetic", eval_iters=400),
                 }
             except Exception as e:   # never lose the headline line to an extra
                 out["extra_workloads"] = {"error": "%s: %s" % (type(e).__name__, e)}

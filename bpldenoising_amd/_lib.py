@@ -47,6 +47,7 @@ class BpltvStats(C.Structure):
         ("collective_ms", C.c_double),
         ("nccl_ranks", C.c_int), ("hb_sync", C.c_int), ("adjoint_chunks", C.c_int),
         ("pdhg_variant", C.c_int),
+        ("ncu", C.c_int), ("launch_chains", C.c_int), ("sweep_shards", C.c_int),
     ]
 
     def as_dict(self):
@@ -70,6 +71,7 @@ SYMBOLS = {
     "bpltv_set_data": (C.c_int, [_H, _dp, _dp]),
     "bpltv_set_data_device": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "bpltv_denoise": (C.c_int, [_H, _dp, C.c_int, C.c_int, _PP, _dp]),
+    "bpltv_denoise_device": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, _PP]),
     "bpltv_evaluate": (C.c_int, [_H, _dp, C.c_int, C.c_int, C.c_double, _PP, _dp, _dp, _dp]),
     "bpltv_sumregs_default_params": (C.c_int, [_PP]),
     "bpltv_sumregs_denoise": (C.c_int, [_H, _dp, C.c_int, C.c_int, _PP, _dp]),

@@ -451,6 +451,41 @@ int upload_alpha(bpltv_t* h, const double* alpha, int am, int an) {
     return BPLTV_OK;
 }
 
+// The same for a parameter that already lives in HBM (bpltv_denoise_device): copied device to device, checked by
+// alpha_check_kernel (one 16-byte read back).
+int upload_alpha_device(bpltv_t* h, const double* d_alpha, int am, int an) {
+    if (!d_alpha || am < 1 || an < 1) return set_err(h, BPLTV_E_ARG, "alpha: null pointer or empty shape");
+    if (am > h->M || an > h->N)
+        return set_err(h, BPLTV_E_ARG, "alpha shape %dx%d exceeds image %dx%d", am, an, h->M, h->N);
+    const size_t need = (size_t)am * an;
+    if (h->alpha_cap < need) {
+        drop_graphs(h);
+        int rc = ensure(h, &h->d_alpha, &h->alpha_cap, need);
+        if (rc) return rc;
+    }
+    if (h->partial_cap < need + 1) {
+        int rc = ensure(h, &h->d_partial, &h->partial_cap, need + 1);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_alpha, d_alpha, need * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    unsigned long long* chk_d = reinterpret_cast<unsigned long long*>(h->d_scalar + 2);
+    HIPCHK(h, hipMemsetAsync(chk_d, 0xFF, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(chk_d + 1, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(alpha_check_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, 1024)), dim3(256), 0, h->stream, h->d_alpha, need, chk_d);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long chk_h[2] = {0, 1};
+    HIPCHK(h, hipMemcpyAsync(chk_h, chk_d, sizeof(chk_h), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (chk_h[1] != 0) return set_err(h, BPLTV_E_ARG, "alpha (device array): parameters must be finite and >= 0");
+    double chk[1];
+    std::memcpy(chk, chk_h, sizeof(double));
+    h->alpha_min = chk[0];
+    h->last_am = am;
+    h->last_an = an;
+    h->last_slices = 1;
+    return BPLTV_OK;
+}
+
 struct Plan {
     int variant, T, nTi, nTj, grid, chains;
 };
@@ -793,6 +828,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     }
     if (rc) return rc;
     h->st.tile_iters = pl.T;
+    h->st.launch_chains = 1;
     h->st.pdhg_variant = pl.variant + 1;
     h->st.tiles = pl.grid;
     h->st.region_i = kVariants[pl.variant].RI;
@@ -863,6 +899,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
                     rc = launch_chains(h, ex, nl >= 128);
                     if (rc) return rc;
                 }
+                h->st.launch_chains = (int)ex.size();
                 buf = (nl - 1) % 2 == 0 ? 0 : 1;  // launch 0 writes set 0, launch l writes set l%2
                 launches = nl * (int)ex.size() + (chain_out_of_phase(main_iters, pl.T, from_state) ? (int)ex.size() / 2 : 0);
                 h->st.graph_used = 1;
@@ -1511,7 +1548,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (nTi < 1 || nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
     const int grid = nTi * nTj * h->O;
     h->st.tile_iters = T; h->st.tiles = grid; h->st.region_i = SR_R; h->st.region_j = SR_R; h->st.pdhg_variant = vi + 1;
-    h->st.launches = 0; h->st.iterations = p.maxiter; h->st.graph_used = 0; h->st.last_gap = -1.0;
+    h->st.launches = 0; h->st.iterations = p.maxiter; h->st.graph_used = 0; h->st.last_gap = -1.0; h->st.launch_chains = 1;
     if (p.maxiter == 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_sr[0][0], h->d_f, h->tot * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         for (int c = 1; c < 7; ++c) HIPCHK(h, hipMemsetAsync(h->d_sr[0][c], 0, h->tot * sizeof(double), h->stream));
@@ -1616,6 +1653,7 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
                 rc = launch_chains(h, exs, nl >= 128);   // short sequences: a helper thread costs more than it hides
                 if (rc) return rc;
             }
+            h->st.launch_chains = (int)exs.size();
             h->st.graph_used = 1;
             done = true;
         }
@@ -2236,6 +2274,7 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount;
+        h->st.ncu = h->ncu;
     }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
@@ -2372,6 +2411,27 @@ int bpltv_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_p
                                  h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    h->st.total_ms = wt.ms();
+    return BPLTV_OK;
+}
+
+int bpltv_denoise_device(bpltv_t* h, const double* d_alpha, int am, int an, const bpltv_params* pp) {
+    if (!h) return BPLTV_E_ARG;
+    if (h->multi) {
+        const int rc = multi_unsupported(h, "bpltv_denoise_device");
+        if (rc >= 0) return rc;
+        const int r = bpltv_denoise_device(h->multi->shard[0], d_alpha, am, an, pp);
+        if (r) h->err = h->multi->shard[0]->err; else { h->has_result = true; multi_stats(h); }
+        return r;
+    }
+    WallTimer wt;
+    HIPCHK(h, hipSetDevice(h->device));
+    bpltv_params p = resolve(pp);
+    if (int prc = check_params(h, p)) return prc;
+    int rc = upload_alpha_device(h, d_alpha, am, an);
+    if (rc) return rc;
+    rc = run_pdhg(h, p);
+    if (rc) return rc;
     h->st.total_ms = wt.ms();
     return BPLTV_OK;
 }

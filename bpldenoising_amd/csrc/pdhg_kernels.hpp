@@ -1017,6 +1017,33 @@ __global__ __launch_bounds__(256) void gap_final_kernel(const double* __restrict
 }
 
 // dtype = 32 handles: narrowing of the kernel's inputs, widening of its result.  grid-stride, block 256.
+// Parameter check on the device (bpltv_denoise_device): out[0] = bit pattern of the smallest valid entry (non-negative
+// doubles order like their bits; preset to all ones), out[1] != 0 if an entry is not finite or negative -- the check
+// the host entry points run on the host array.  Grid-stride, one atomic pair per workgroup.
+__global__ __launch_bounds__(256) void alpha_check_kernel(const double* __restrict__ a, size_t n, unsigned long long* __restrict__ out) {
+    __shared__ double smin[4];
+    __shared__ int sbad[4];
+    double mn = __builtin_huge_val();
+    int bad = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const double v = a[e];
+        if (!(v >= 0.0) || !(v < __builtin_huge_val())) bad = 1;   // NaN, negative, infinite
+        else mn = fmin(mn, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fmin(mn, __shfl_down(mn, off));
+        bad |= __shfl_down(bad, off);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smin[w] = mn; sbad[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+        atomicMin(out, (unsigned long long)__double_as_longlong(m));
+        if (sbad[0] | sbad[1] | sbad[2] | sbad[3]) atomicOr(out + 1, 1ull);
+    }
+}
+
 __global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) dst[e] = (float)src[e];
 }

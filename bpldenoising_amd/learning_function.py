@@ -158,6 +158,12 @@ class TVSolver:
         self._check(self._lib.bpltv_denoise(self._h, _ptr(a), am, an, C.byref(p), _ptr(u) if fetch else None))
         return u
 
+    def denoise_device(self, alpha_ptr, am=1, an=1, **kw):
+        """bpltv_denoise_device: the parameter (am x an doubles, column major) already resident in HBM at `alpha_ptr`
+        (e.g. a torch tensor's .data_ptr()); the result stays on the device (u_device_ptr / copy_u_device)."""
+        p = self.params(**kw)
+        self._check(self._lib.bpltv_denoise_device(self._h, C.c_void_p(alpha_ptr), int(am), int(an), C.byref(p)))
+
     def evaluate(self, x, delta, fetch_u=True, **kw):
         a, am, an, scalar = _alpha_arg(x)
         self._last_npar = am * an

@@ -145,6 +145,11 @@ typedef struct bpltv_stats {
     int pdhg_variant;          /* 1-based index of the PDHG kernel the last solve ran (the variant table of
                                   csrc/bpltv.hip: 1..15 pdhg_tile_kernel, 16..18 pdhg_wave_kernel, 19.. pdhg_rows_kernel;
                                   sum of regularisers: 1 sr_tile_kernel, 2 sr_strip_kernel)                      */
+    int ncu;                   /* compute units of the device (hipDeviceProp_t.multiProcessorCount): what bench.py prices
+                                  the VALU issue floor against                                                   */
+    int launch_chains;         /* independent launch chains (image groups replayed concurrently) of the last solve */
+    int sweep_shards;          /* last bpltv_sweep of a multi handle: devices the K parameter blocks were split over
+                                  (replica mode), 0 = the images were split / single device                        */
 } bpltv_stats_t;
 
 #define BPLTV_RESIDUAL_GATE 1e-6
@@ -189,6 +194,13 @@ int bpltv_set_data_device(bpltv_t *h, const double *d_ubar, const double *d_f);
  * u_out: host, M*N*O doubles, or NULL to leave the result on the device (bpltv_u_device). */
 int bpltv_denoise(bpltv_t *h, const double *alpha, int am, int an, const bpltv_params *p,
                   double *u_out);
+
+/* The same solve with the parameter already resident in HBM (d_alpha: device pointer, am*an doubles, column major) and
+ * the result left there (bpltv_u_device): no host array crosses the boundary, which is how bench.py times a pixel-map
+ * parameter (8 MiB for 1024 x 1024) without a PCIe copy in the timed region.  The entries are checked on the device
+ * (finite, >= 0) exactly as bpltv_denoise checks a host array.  Single-device handles (multi: BPLTV_E_UNSUPPORTED beyond
+ * one shard). */
+int bpltv_denoise_device(bpltv_t *h, const double *d_alpha, int am, int an, const bpltv_params *p);
 
 /* tv_op_learning_function(x, data, D): src/TVLearningFunctionVec.jl:14-27.
  * cost_out: 1 double; grad_out: am*an doubles; u_out: host M*N*O doubles or NULL. */

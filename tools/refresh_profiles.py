@@ -104,7 +104,8 @@ def publish(tag):
     copied = []
     for sub, name in (("kt_bench", "kernel_stats_bench"), ("kt_cfg5", "kernel_stats_cfg5_pdhg"),
                       ("kt_eval128", "kernel_stats_evaluate_128"), ("kt_evalcfg5", "kernel_stats_cfg5_evaluate"),
-                      ("kt_nd", "kernel_stats_nd_unit_1024x8"), ("kt_sumregs", "kernel_stats_sumregs")):
+                      ("kt_nd", "kernel_stats_nd_unit_1024x8"), ("kt_sumregs", "kernel_stats_sumregs"),
+                      ("kt_single", "kernel_stats_single_image")):
         ks = newest(os.path.join(sub, "**", "*kernel_stats.csv"))
         if ks:
             shutil.copy(ks, os.path.join(PRO, "%s_%s.csv" % (tag, name))); copied.append(name)
@@ -116,11 +117,14 @@ def publish(tag):
                       ("pmc_evalcfg5_sq2", "pmc_sq2_cfg5_evaluate"), ("pmc_evalcfg5_fetch", "pmc_fetch_cfg5_evaluate"),
                       ("pmc_evalcfg5_write", "pmc_write_cfg5_evaluate"), ("pmc_bench_fetch", "pmc_fetch_pdhg"),
                       ("pmc_bench_write", "pmc_write_pdhg"), ("pmc_cfg5_fetch", "pmc_fetch_cfg5_pdhg"),
-                      ("pmc_cfg5_write", "pmc_write_cfg5_pdhg"), ("pmc_hb_sq", "pmc_hb_lu_unit")):
+                      ("pmc_cfg5_write", "pmc_write_cfg5_pdhg"), ("pmc_hb_sq", "pmc_hb_lu_unit"),
+                      ("pmc_single_sq1", "pmc_sq_single_image"), ("pmc_single_fetch", "pmc_fetch_single_image"),
+                      ("pmc_single_write", "pmc_write_single_image"), ("pmc_sumregs_sq1", "pmc_sq_sumregs"),
+                      ("pmc_sumregs_sq2", "pmc_sq2_sumregs")):
         p = newest(os.path.join(sub, "**", "pmc_summary.csv"))
         if p:
             shutil.copy(p, os.path.join(PRO, "%s_%s_summary.csv" % (tag, name))); copied.append(name)
-    for log, name in (("bench.log", "bench_line"), ("bench_cfg5.log", "bench_line_cfg5"), ("bench_f32.log", "bench_line_f32"),
+    for log, name in (("bench.log", "bench_line"), ("bench_cfg5.log", "bench_line_cfg5"), ("bench_single.log", "bench_line_single"), ("bench_f32.log", "bench_line_f32"),
                       ("bench_cfg5_f32.log", "bench_line_cfg5_f32")):
         p = os.path.join(SRC, log)
         if os.path.exists(p):
@@ -145,7 +149,8 @@ def publish(tag):
             pass
     tj["correction"] = ("gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled (MI355X_MICROARCH.md, section HBM); "
                         "WRITE_SIZE exact; both in KiB per dispatch")
-    for key, pre, line in (("10x128x128 scalar", "pmc_bench", "bench_line"), ("8x1024x1024 map", "pmc_cfg5", "bench_line_cfg5")):
+    for key, pre, line in (("10x128x128 scalar", "pmc_bench", "bench_line"), ("8x1024x1024 map", "pmc_cfg5", "bench_line_cfg5"),
+                           ("1x128x128 scalar", "pmc_single", "bench_line_single")):
         fe = pmc_mean(pre + "_fetch", "pdhg_", "FETCH_SIZE")      # pdhg_tile_kernel or pdhg_rows_kernel: the one with most dispatches
         wr = pmc_mean(pre + "_write", "pdhg_", "WRITE_SIZE")
         vi = pmc_mean(pre + "_sq1", "pdhg_", "SQ_INSTS_VALU")
@@ -160,7 +165,7 @@ def publish(tag):
             "valu_wave_instructions_per_launch": vi,
             # the counter passes launch the whole grid eagerly; the bench line's dispatch holds 1 / launch_chains of it
             "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"] * b["roofline"].get("launch_chains", 1),
-            "source": "tools/prof2.sh / prof3.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
+            "source": "tools/prof2.sh / prof3.sh / prof4.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, eager launches: --no-graph) of the bench command",
         }
     json.dump(tj, open(tf, "w"), indent=1)
     print("published:", ", ".join(copied))
