@@ -358,6 +358,51 @@ def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, eval
     return out
 
 
+def sweep_bench(args, TVSolver, shard_range, torch):
+    """`--sweep K`: generate_cost of /root/reference/src/BPLDenoising.jl:92-111 -- K parameters x the images of a dataset,
+    TVDenoise each -- as ONE bpltv_sweep through a handle over --gpus devices.  The reference's default is ONE image
+    (num_samples = 1, :313; cameraman_128_10 holds one pair), so the K parameter blocks are what the devices share:
+    shard_range(K, n) blocks per device on replicas of the dataset.  One JSON line: solves/s (a solve = one ROF problem
+    run for --iters iterations), the per-device parameter ranges, what the library reports (stats.sweep_shards)."""
+    import numpy as np
+    K, n = args.sweep, args.gpus
+    M = N = args.size
+    images = args.images if args.images != 10 or args.data != "auto" else 1     # default: the one-image case
+    data = "cameraman_128_10" if (args.data == "auto" and M == 128) else args.data
+    ub, f, label = load_batch(data, images, N, M, 20211004)
+    iters = args.iters if args.iters != 5000 else 10000                          # TVDenoise: maxiter = 10000 (:47)
+    alphas = np.linspace(0.005, 0.5, K)
+    if n == 1 and not args.one_device:
+        s = TVSolver(M, N, images, device=0)
+    elif args.one_device:
+        s = TVSolver(M, N, images, devices=[0] * n)
+    else:
+        s = TVSolver(M, N, images, ngpus=n)
+    s.set_data(ub, f)
+    for _ in range(max(1, args.warmup)):
+        costs = s.sweep(alphas, maxiter=iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        costs = s.sweep(alphas, maxiter=iters)
+    T = time.perf_counter() - t0
+    st = s.stats()
+    nsh = st["sweep_shards"]
+    ranges = [list(shard_range(K, nsh, r)) for r in range(nsh)] if nsh else None
+    out = {"metric": "parameter-sweep ROF solves/s (extra mode; BASELINE's metric is the default run)",
+           "value": args.steps * K * images / T, "unit": "solves/s (one solve = %d PDHG iterations of one %dx%d image)" % (iters, N, M),
+           "n_gpus": n, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": 1e3 * T / args.steps,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": label,
+           "config": {"workload": "bpltv_sweep: %d scalar parameters x %d image(s) %dx%d, %d iterations each" % (K, images, N, M, iters)},
+           "sweep": {"K": K, "images": images, "split": "parameters over replicas" if nsh else ("images over shards" if st["shards"] > 1 else "single device"),
+                     "sweep_shards": nsh, "parameter_ranges_per_device": ranges, "image_shards": st["shards"],
+                     "devices_distinct": st["ngpus"], "pdhg_event_ms_max_over_devices": st["pdhg_ms"],
+                     "pdhg_iterations_per_s_of_the_batch": iters / (1e-3 * st["pdhg_ms"]) if st["pdhg_ms"] else None,
+                     "cost_min_at": float(alphas[int(np.argmin(costs))])}}
+    print(json.dumps(out), flush=True)
+    s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,6 +418,10 @@ def main():
     ap.add_argument("--multi-handle", action="store_true",
                     help="one process, one bpltv_create_multi handle over --gpus devices (the Julia drop-in form); "
                          "run as `python bench.py --gpus N --multi-handle`, no launcher")
+    ap.add_argument("--sweep", type=int, default=0, metavar="K",
+                    help="forward-only parameter sweep instead of the headline workload: K scalar parameters x the dataset's images x "
+                         "--iters iterations through ONE handle over --gpus devices (bpltv_sweep; one-image sets split the parameters "
+                         "over replicas); reports solves/s -- an extra mode, not BASELINE's metric; no launcher")
     ap.add_argument("--evaluate", action="store_true", help="time full evaluate (loss + adjoint gradient + all-reduce)")
     ap.add_argument("--tile-iters", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
@@ -391,7 +440,7 @@ def main():
                          "faces_val_128_10 | cameraman_128_10 | circle_128_10 | synthetic")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.multi_handle:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.multi_handle and not args.sweep:
         sys.exit(self_launch(args.gpus))
 
     import numpy as np
@@ -401,7 +450,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and not args.multi_handle:
+    if world != args.gpus and not args.multi_handle and not args.sweep:
         if world == 1 and args.gpus > 1:
             print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus, file=sys.stderr)
             sys.exit(2)
@@ -487,6 +536,10 @@ def main():
             elif s is not None:
                 s.denoise(alpha, fetch=False, **kw)
         return step
+
+    if args.sweep:
+        sweep_bench(args, TVSolver, shard_range, torch)
+        return
 
     multi_info = None
     if args.multi_handle:

@@ -268,6 +268,18 @@ struct MultiState {
     std::vector<double*> d_rows, d_all;                  // all-gather send / receive buffers per shard
     std::vector<size_t> rows_cap;                        // doubles per row buffer, per shard (a failed allocation on one
                                                          // shard leaves the others' buffers and capacities consistent)
+    // Parameter sweeps have a second data-parallel axis (the K parameter blocks): REPLICAS -- one handle per device the
+    // caller asked for, each holding ALL O images -- let a dataset with fewer images than devices (the reference's default
+    // num_samples = 1, /root/reference/src/BPLDenoising.jl:313; cameraman_128_10 holds one pair) use every device.
+    // Created on the first sweep that splits the parameters (multi_sweep), filled from the shards' resident data.
+    int dtype = 64;
+    std::vector<int> req_dev;                            // every requested device, also those beyond min(nshards, O)
+    std::vector<bpltv_t*> rep;                           // replica r lives on req_dev[r]; rep[0] == shard[0] when one shard holds everything
+    std::vector<ShardWorker*> rep_worker;                // worker[r] for r < shards, an owned one beyond
+    std::vector<std::unique_ptr<ShardWorker>> rep_owned;
+    bool rep_data = false;                               // the replicas hold the current dataset
+    int sweep_split = 0;                                 // bpltv_set_option "sweep_split": 0 automatic, 1 images, 2 parameters
+    bool rep_borrowed0() const { return !rep.empty() && !shard.empty() && rep[0] == shard[0]; }
 };
 
 namespace {
@@ -1952,6 +1964,14 @@ void multi_free(bpltv_t* h) {
             return BPLTV_OK;
         });
     }
+    for (size_t r = 0; r < ms->rep.size(); ++r) {   // replicas (not the borrowed shard 0), each on its device's thread
+        if (!ms->rep[r] || (r == 0 && ms->rep_borrowed0())) continue;
+        bpltv_t* c = ms->rep[r];
+        ms->rep_worker[r]->post([c]() -> int { (void)bpltv_destroy(c); return 0; });
+        (void)ms->rep_worker[r]->wait();
+    }
+    ms->rep.clear();
+    ms->rep_owned.clear();
     for (ncclComm_t c : ms->comm) (void)ncclCommDestroy(c);
     ms->worker.clear();   // joins the threads
     (void)n;
@@ -1979,7 +1999,9 @@ int multi_create(bpltv_t** out, int M, int N, int O, const int* devices, int nsh
     MultiState* ms = new (std::nothrow) MultiState();
     if (!ms) return set_err(h, BPLTV_E_NOMEM, "out of host memory");
     h->multi = ms;
-    const int n = std::min(nshards, O);   // no empty shards: 1 image cannot use more than one GPU
+    ms->dtype = dtype;
+    ms->req_dev.assign(devices, devices + nshards);
+    const int n = std::min(nshards, O);   // no empty image shards; parameter sweeps use the other devices too (replicas)
     std::set<int> distinct;
     for (int k = 0; k < n; ++k) {
         int lo, hi;
@@ -2038,13 +2060,95 @@ int multi_stats(bpltv_t* h) {   // aggregate the shards' statistics into h->st
     return BPLTV_OK;
 }
 
+// Run f(r, replica r) on the worker thread of replica r's device, r < cnt, and wait for all of them.
+template <class F>
+int rep_run(bpltv_t* h, int cnt, F f) {
+    MultiState& ms = *h->multi;
+    for (int r = 0; r < cnt; ++r) ms.rep_worker[r]->post([&f, &ms, r]() -> int { return f(r, ms.rep[r]); });
+    int rc = BPLTV_OK, bad = -1;
+    for (int r = 0; r < cnt; ++r) {
+        const int q = ms.rep_worker[r]->wait();
+        if (q != BPLTV_OK && rc == BPLTV_OK) { rc = q; bad = r; }
+    }
+    if (rc != BPLTV_OK)
+        set_err(h, rc, "replica %d (all %d images, device %d): %s", bad, h->O, ms.req_dev[bad], ms.rep[bad] ? ms.rep[bad]->err.c_str() : "creation failed");
+    return rc;
+}
+
+// Make sure `want` replicas exist and hold the dataset.  A replica is an ordinary single-device handle over all O
+// images; the dataset comes from the shards' resident copies through the host (once per bpltv_set_data -- the library
+// keeps no host pointer of the caller's).
+int multi_replicas_ready(bpltv_t* h, int want) {
+    MultiState& ms = *h->multi;
+    const int n = (int)ms.shard.size();
+    const int have = (int)ms.rep.size();
+    if (want > (int)ms.req_dev.size()) return set_err(h, BPLTV_E_ARG, "replicas: %d wanted, %zu devices requested", want, ms.req_dev.size());
+    if (want > have) {
+        for (int r = have; r < want; ++r) {
+            ms.rep.push_back(nullptr);
+            if (r < n) ms.rep_worker.push_back(ms.worker[r].get());
+            else {
+                ms.rep_owned.emplace_back(new ShardWorker(ms.req_dev[r]));
+                ms.rep_worker.push_back(ms.rep_owned.back().get());
+            }
+        }
+        const int M = h->M, N = h->N, O = h->O;
+        int rc = rep_run(h, want, [&ms, M, N, O, n, have](int r, bpltv_t*) -> int {
+            if (r < have) return BPLTV_OK;
+            if (r == 0 && n == 1) { ms.rep[0] = ms.shard[0]; return BPLTV_OK; }   // one shard holds every image already
+            const int rc2 = bpltv_create(&ms.rep[r], M, N, O, ms.req_dev[r], ms.dtype);
+            if (rc2 == BPLTV_OK) ms.rep[r]->opt = ms.shard[0]->opt;
+            return rc2;
+        });
+        if (rc) {   // leave no half-made replica behind: a later call starts from `have` again
+            for (int r = want - 1; r >= have; --r) {
+                bpltv_t* c = ms.rep[r];
+                if (c && !(r == 0 && n == 1)) {
+                    ms.rep_worker[r]->post([c]() -> int { (void)bpltv_destroy(c); return 0; });
+                    (void)ms.rep_worker[r]->wait();
+                }
+                ms.rep.pop_back();
+                ms.rep_worker.pop_back();
+                if (r >= n) ms.rep_owned.pop_back();
+            }
+            return rc;
+        }
+        ms.rep_data = false;
+        std::set<int> distinct(ms.dev.begin(), ms.dev.end());
+        for (int r = 0; r < want; ++r) distinct.insert(ms.req_dev[r]);
+        h->st.ngpus = (int)distinct.size();
+    }
+    if (!ms.rep_data) {
+        if (!h->has_data) return set_err(h, BPLTV_E_NODATA, "bpltv_set_data has not been called");
+        std::vector<double> ub(h->tot), f(h->tot);
+        const size_t npx = h->npx;
+        int rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
+            HIPCHK(c, hipMemcpy(ub.data() + ms.lo[k] * npx, c->d_ubar, c->tot * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(f.data() + ms.lo[k] * npx, c->d_f, c->tot * sizeof(double), hipMemcpyDeviceToHost));
+            return BPLTV_OK;
+        });
+        if (rc) return rc;
+        rc = rep_run(h, (int)ms.rep.size(), [&](int r, bpltv_t* c) { return (r == 0 && ms.rep_borrowed0()) ? BPLTV_OK : bpltv_set_data(c, ub.data(), f.data()); });
+        if (rc) return rc;
+        ms.rep_data = true;
+    }
+    return BPLTV_OK;
+}
+
 int multi_set_data(bpltv_t* h, const double* ubar, const double* f) {
     if (!ubar || !f) return set_err(h, BPLTV_E_ARG, "set_data: null pointer");
     MultiState& ms = *h->multi;
     const size_t npx = h->npx;
     int rc = multi_run(h, [&](int k, bpltv_t* c) { return bpltv_set_data(c, ubar + ms.lo[k] * npx, f + ms.lo[k] * npx); });
-    if (rc == BPLTV_OK) h->has_data = true;
-    return rc;
+    if (rc) return rc;
+    h->has_data = true;
+    ms.rep_data = false;
+    if (!ms.rep.empty()) {   // replicas exist already: they take the whole dataset from the caller's arrays
+        rc = rep_run(h, (int)ms.rep.size(), [&](int r, bpltv_t* c) { return (r == 0 && ms.rep_borrowed0()) ? BPLTV_OK : bpltv_set_data(c, ubar, f); });
+        if (rc) return rc;
+        ms.rep_data = true;
+    }
+    return BPLTV_OK;
 }
 
 int multi_denoise(bpltv_t* h, const double* alpha, int am, int an, const bpltv_params* pp, double* u_out, int slices = 1) {
@@ -2191,10 +2295,50 @@ int multi_gradient(bpltv_t* h, const double* u, const double* ubar, const double
 int multi_sweep(bpltv_t* h, const double* alphas, int K, int am, int an, const bpltv_params* pp, double* cost_out,
                 double* u_out) {
     if (!alphas || !cost_out || K < 1) return set_err(h, BPLTV_E_ARG, "sweep: null pointer or K < 1");
+    if (am < 1 || an < 1 || am > h->M || an > h->N) return set_err(h, BPLTV_E_ARG, "sweep: bad parameter shape %dx%d", am, an);
     WallTimer wt;
     MultiState& ms = *h->multi;
     const int n = (int)ms.shard.size();
     const size_t npx = h->npx;
+    h->st.sweep_shards = 0;
+    {
+        // Which axis to split: the images (what the shards already hold: device k solves K x O_k problems) or the K
+        // parameter blocks over replicas (device r solves K_r x O problems).  Automatic = the smaller largest share;
+        // ties keep the image split (no second copy of the dataset).  The reference's sweeps
+        // (/root/reference/src/BPLDenoising.jl:92-111,136-158,381-415) run on num_samples = 1 by default (:313), where
+        // only the parameter axis can use more than one device.
+        const int nrep = (int)std::min<size_t>(ms.req_dev.size(), (size_t)K);
+        const long share_img = (long)K * ms.maxloc, share_par = (long)((K + nrep - 1) / nrep) * h->O;
+        const bool by_par = ms.sweep_split == 2 || (ms.sweep_split == 0 && share_par < share_img);
+        if (by_par && nrep >= 1 && !(n == 1 && nrep == 1)) {
+            int rc = multi_replicas_ready(h, nrep);
+            if (rc) return rc;
+            const size_t npar = (size_t)am * an;
+            rc = rep_run(h, nrep, [&](int r, bpltv_t* c) -> int {
+                int lo, hi;
+                shard_range(K, nrep, r, &lo, &hi);
+                // parameter-major outputs: replica r's blocks [lo, hi) are contiguous in cost_out and u_out
+                return bpltv_sweep(c, alphas + (size_t)lo * npar, hi - lo, am, an, pp, cost_out + lo,
+                                   u_out ? u_out + (size_t)lo * h->O * npx : nullptr);
+            });
+            if (rc) return rc;
+            bpltv_stats_t a = ms.rep[0]->st;
+            for (int r = 1; r < nrep; ++r) {
+                const bpltv_stats_t& b = ms.rep[r]->st;
+                a.tiles += b.tiles;
+                a.launches = std::max(a.launches, b.launches);
+                a.pdhg_ms = std::max(a.pdhg_ms, b.pdhg_ms);
+                a.algorithmic_bytes += b.algorithmic_bytes;
+                a.iterations = std::max(a.iterations, b.iterations);
+            }
+            a.O = h->O; a.ngpus = h->st.ngpus; a.shards = h->st.shards; a.nccl_ranks = h->st.nccl_ranks;
+            a.collective = 0; a.collective_ms = 0.0;
+            a.sweep_shards = nrep;
+            a.total_ms = wt.ms();
+            h->st = a;
+            return BPLTV_OK;
+        }
+    }
     std::vector<double> cost((size_t)n * K);
     std::vector<std::vector<double>> ubuf(n);
     int rc = multi_run(h, [&](int k, bpltv_t* c) -> int {
@@ -2734,8 +2878,18 @@ int bpltv_set_option(bpltv_t* h, const char* name, double value) {
     if (!name || !std::isfinite(value)) return set_err(h, BPLTV_E_ARG, "set_option: null name or non-finite value");
     if (h->multi) {
         const std::string nm(name);
-        return multi_run(h, [&](int, bpltv_t* c) { return bpltv_set_option(c, nm.c_str(), value); });
+        if (nm == "sweep_split") {
+            const int v = (int)value;
+            if (v < 0 || v > 2) return set_err(h, BPLTV_E_ARG, "set_option(sweep_split): 0 automatic, 1 images, 2 parameters");
+            h->multi->sweep_split = v;
+            return BPLTV_OK;
+        }
+        int rc = multi_run(h, [&](int, bpltv_t* c) { return bpltv_set_option(c, nm.c_str(), value); });
+        if (rc == BPLTV_OK && !h->multi->rep.empty())
+            rc = rep_run(h, (int)h->multi->rep.size(), [&](int r, bpltv_t* c) { return (r == 0 && h->multi->rep_borrowed0()) ? BPLTV_OK : bpltv_set_option(c, nm.c_str(), value); });
+        return rc;
     }
+    if (std::string(name) == "sweep_split") return BPLTV_OK;   // single-device handle: nothing to split
     HIPCHK(h, hipSetDevice(h->device));
     const std::string nm(name);
     const int iv = (int)value;

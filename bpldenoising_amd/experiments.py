@@ -226,11 +226,22 @@ def _dataset(dataset_name, num_samples, datasets_root, npz):
     return np.ascontiguousarray(true_), np.ascontiguousarray(data)
 
 
+def _use(ngpus, devices):
+    """ngpus / devices of the sweep and validation drivers: the in-library multi-device handle behind the reference-named
+    entry points (learning_function.use_devices).  With num_samples = 1 -- the reference's default, src/BPLDenoising.jl:313
+    -- the K parameters of a sweep are what is split over the devices (bpltv_sweep, replica mode)."""
+    if ngpus is not None or devices is not None:
+        from .learning_function import use_devices
+        use_devices(ngpus=ngpus, devices=devices)
+
+
 def generate_scalar_tv_cost(dataset_name, parameter_range, num_samples=1, datasets_root=None, npz=None, out_root=None,
-                            **solver_kwargs):
+                            ngpus=None, devices=None, **solver_kwargs):
     """costs[i] = L2CostFunction(TVDenoise(data, parameter_range[i]), true): all parameters as ONE batch of
-    K*O problems on the GPU (bpltv_sweep).  Saved as <dataset>_cost.npz (the reference writes JLD2)."""
+    K*O problems on the GPU (bpltv_sweep; over `ngpus` devices the parameters or the images are split, whichever
+    leaves the smaller share per device).  Saved as <dataset>_cost.npz (the reference writes JLD2)."""
     from .learning_function import generate_cost
+    _use(ngpus, devices)
     full = _full(dataset_name)
     true_, data = _dataset(dataset_name, num_samples, datasets_root, npz)
     parameter_range = np.asarray(parameter_range, dtype=np.float64)
@@ -242,9 +253,10 @@ def generate_scalar_tv_cost(dataset_name, parameter_range, num_samples=1, datase
 
 
 def generate_2d_tv_cost(dataset_name, parameter_range_1, parameter_range_2, num_samples=1, datasets_root=None, npz=None,
-                        out_root=None, **solver_kwargs):
+                        out_root=None, ngpus=None, devices=None, **solver_kwargs):
     """costs[i, j] for the 2 x 1 patch parameter [p1[i]; p2[j]] (src/BPLDenoising.jl:136-158)."""
     from .learning_function import generate_cost
+    _use(ngpus, devices)
     full = _full(dataset_name)
     true_, data = _dataset(dataset_name, num_samples, datasets_root, npz)
     p1 = np.asarray(parameter_range_1, dtype=np.float64); p2 = np.asarray(parameter_range_2, dtype=np.float64)
@@ -258,8 +270,11 @@ def generate_2d_tv_cost(dataset_name, parameter_range_1, parameter_range_2, num_
 
 
 def validate_tv_parameter(parameter, dataset_name="cameraman_128_5", datasets_root=None, npz=None, out_root=None,
-                          denoise_function=None, **solver_kwargs):
-    """TVDenoise of the whole validation set with a learned parameter; cost + quality table + PNGs."""
+                          denoise_function=None, ngpus=None, devices=None, **solver_kwargs):
+    """TVDenoise of the whole validation set with a learned parameter; cost + quality table + PNGs
+    (src/BPLDenoising.jl:381-415).  Over `ngpus` devices the images of the set are sharded (forward solves only: no
+    collective)."""
+    _use(ngpus, devices)
     if denoise_function is None:
         from .learning_function import TVDenoise as denoise_function
     full = _full(dataset_name)

@@ -293,6 +293,29 @@ class TVSolver:
 # because bilevel_learn passes the same `ds` to every evaluation (/root/reference/src/TRBox.jl:210,227).
 # ---------------------------------------------------------------------------------------------
 _cache = {}
+_devices = {"ngpus": None, "devices": None}
+
+
+def use_devices(ngpus=None, devices=None):
+    """Devices behind the reference-named entry points below: None (default) = one GPU; `ngpus` = one in-library handle
+    over that many devices (bpltv_create_multi: images sharded for evaluate / denoise, and -- a dataset with fewer
+    images than devices, the reference's default num_samples = 1 -- the parameters of a sweep split over replicas);
+    `devices` = explicit placement (bpltv_create_sharded; a repeated device rehearses the path on one GPU).  The
+    environment variable BPLTV_NGPUS sets the same default the Julia glue reads."""
+    new = {"ngpus": None if ngpus is None else int(ngpus), "devices": None if devices is None else [int(d) for d in devices]}
+    if new != _devices:
+        clear_cache()
+        _devices.update(new)
+
+
+def _device_kwargs():
+    if _devices["devices"] is not None:
+        return {"devices": _devices["devices"]}
+    if _devices["ngpus"] is not None:
+        return {"ngpus": _devices["ngpus"]}
+    import os
+    e = os.environ.get("BPLTV_NGPUS")
+    return {"ngpus": int(e)} if e and int(e) != 1 else {}
 
 
 def _fingerprint(a):
@@ -307,7 +330,7 @@ def _solver_for(ubar, f):
     not on the `[None]` / `asarray` views made here, which are new objects on every call -- keeps references
     to them (so a later array cannot reuse their id()), and re-uploads when their content fingerprint
     changed (in-place edits between calls)."""
-    key = (id(ubar), id(f))
+    key = (id(ubar), id(f), repr(_device_kwargs()))
     fp = (None if ubar is None else _fingerprint(ubar), _fingerprint(f))
     ent = _cache.get("s")
     if ent is not None and ent["key"] == key and ent["fp"] == fp:
@@ -323,7 +346,7 @@ def _solver_for(ubar, f):
     if s is None or (s.M, s.N, s.O) != (M, N, O):
         if s is not None:
             s.close()
-        s = TVSolver(M, N, O)
+        s = TVSolver(M, N, O, **_device_kwargs())
     s.set_data(u3, f3)
     _cache["s"] = {"key": key, "fp": fp, "solver": s, "refs": (ubar, f)}
     return s

@@ -176,7 +176,8 @@ int bpltv_create(bpltv_t **h, int M, int N, int O, int device, int dtype);
  * (set_data_device, evaluate_device, u_device, copy_u_device) return BPLTV_E_UNSUPPORTED on more than one shard.
  * Status: verified with ngpus = 1 (a one-rank communicator) and with several shards on one device (host sum); the
  * collectives over ngpus > 1 have not yet run on hardware -- tests/test_gpu_multi.py holds the checks that switch on
- * when two or more devices are visible.  stats.nccl_ranks reports what ncclCommCount says. */
+ * when two or more devices are visible.  stats.nccl_ranks reports what ncclCommCount says.
+ * Devices beyond min(ngpus, O) hold no image shard (one image cannot be split), but bpltv_sweep uses them: see there. */
 int bpltv_create_multi(bpltv_t **h, int M, int N, int O, int ngpus, int dtype);
 /* Explicit placement: shard k of `nshards` runs on HIP device devices[k].  A device may appear more than
  * once (rehearsal of the sharded path on one GPU); RCCL cannot put two ranks on one device, so the collective
@@ -265,7 +266,16 @@ int bpltv_gradient(bpltv_t *h, const double *u, const double *ubar, const double
  * one solve after the other.  Here the K parameter blocks (each am x an, column major, K*am*an
  * doubles) times the O resident images form ONE batch of K*O independent ROF problems -- the second
  * data-parallel axis that fills a GPU even with a single image.  cost_out: K doubles; u_out: NULL
- * or K*M*N*O doubles (parameter-major).  Use maxiter = 10000 for the TVDenoise setting. */
+ * or K*M*N*O doubles (parameter-major).  Use maxiter = 10000 for the TVDenoise setting.
+ * Multi-device handles split whichever axis leaves the smaller largest share per device: the images (device k solves
+ * K x O_k problems on the shard it already holds) or the K parameter blocks (device r solves K_r x O problems on a
+ * REPLICA -- a second, whole copy of the dataset made on every requested device at the first such sweep, filled from
+ * the shards' resident data).  With the reference's default num_samples = 1 (src/BPLDenoising.jl:313) or the one-pair
+ * sets (datasets/cameraman_128_10/filelist.txt) only the parameter axis can use more than one GPU: 100 parameters x 1
+ * image on 8 devices = 13,13,13,13,12,12,12,12 problems per device.  Costs are concatenated (every replica sums over
+ * all O images in image order), u_out slices are written in place: the results are bitwise those of one single-device
+ * handle either way.  bpltv_set_option "sweep_split" (0 automatic, 1 images, 2 parameters) forces an axis;
+ * stats.sweep_shards = devices the parameter blocks were split over (0: image split / single device). */
 int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const bpltv_params *p,
                 double *cost_out, double *u_out);
 
@@ -281,7 +291,8 @@ int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const b
  *                        rocprofv3 run needs), 2 stream memory operations (BPLTV_E_HIP when the device has none)
  *   "hb_single_stream"   1: that solver's three streams folded into one (rocprofv3 --pmc)
  *   "hb_rw"              32 | 128: rows per workgroup of its substitutions (0 = by size)
- * Multi-device handles pass the option to every shard. */
+ *   "sweep_split"        multi-device handles, bpltv_sweep: 0 automatic, 1 split the images, 2 split the parameter blocks
+ * Multi-device handles pass the other options to every shard (and sweep replica). */
 int bpltv_set_option(bpltv_t *h, const char *name, double value);
 
 int bpltv_stats(bpltv_t *h, bpltv_stats_t *out);

@@ -92,3 +92,17 @@ def test_cost_sweeps_and_validation(gpu_solver_cls, oracle, tmp_path):
     assert c2.shape == (2, 1) and np.allclose(c2[:, 0], ref2, rtol=1e-12)
     u, cost, w = E.validate_tv_parameter(0.1, dataset_name="circle", npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=500)
     assert np.array_equal(u, oracle.pdhg(f, 0.1, maxiter=500)) and np.isclose(cost, oracle.cost(u, ub), rtol=1e-13)
+    # the same drivers over a multi-device handle (rehearsed on one GPU with a repeated device): the ONE image of the set
+    # (num_samples = 1, src/BPLDenoising.jl:313) leaves only the parameter axis to split -- replicas, bitwise the same costs
+    import bpldenoising_amd.learning_function as LF
+    try:
+        c1m = E.generate_scalar_tv_cost("circle", rng1, npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=600, devices=[0, 0])
+        assert LF._cache["s"]["solver"].stats()["sweep_shards"] == 2
+        assert np.array_equal(c1m, c1)
+        c2m = E.generate_2d_tv_cost("circle", [0.05, 0.2], [0.1], npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=400, devices=[0, 0])
+        assert np.array_equal(c2m, c2)
+        um, costm, _ = E.validate_tv_parameter(0.1, dataset_name="circle", npz=DATASETS_NPZ, out_root=str(tmp_path), maxiter=500, devices=[0, 0])
+        assert np.array_equal(um, u) and costm == cost
+    finally:
+        LF.use_devices()        # back to one GPU for the tests that follow
+
