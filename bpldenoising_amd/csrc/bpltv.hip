@@ -124,7 +124,6 @@ const Variant kVariants[] = {
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
     //  8 x 1024^2 as well: none beats variant 13)
 };
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 struct GraphKey {
     int maxiter, T, variant, am, an, chains;
@@ -498,117 +497,27 @@ int upload_alpha_device(bpltv_t* h, const double* d_alpha, int am, int an) {
     return BPLTV_OK;
 }
 
-struct Plan {
-    int variant, T, nTi, nTj, grid, chains;
-};
-
+// Region, fusion depth and launch chains of one solve: plan_pdhg (tiling.hpp -- plain C++, fuzzed under the sanitizers
+// by tools/plan_host_check.cpp) over the geometry of the variant table above.
 int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
-    int v = p.reserved[0] - 1;  // explicit variant (1-based), 0 = auto
-    const int M = h->M, N = h->N;
-    if (v < 0) {
-        // Large images: 64-lane rows (pdhg_rows_kernel, variant 19: 64x64 region, 8 px per thread; 20: 64x48 when that
-        // still fits the chip in one round of two workgroups per CU -- measured on 1 ... 16 x 1024^2, 4 x 512^2, 8 x 300^2,
-        // 2 x 2048^2, 3 x 1100x700: 1.2-1.5 x the 48x48 tile kernel); images narrower than a
-        // region keep the 48x48 tile kernel (variant 13).
-        v = 0;
-        if (M > 256 || N > 256) {
-            v = 12;
-            if (M >= 64 && N >= 64) {
-                const int ncu = h->ncu > 0 ? h->ncu : 256;
-                auto tiles = [&](int vv) { return (double)tile_count(M, kVariants[vv].RI, 8) * tile_count(N, kVariants[vv].RJ, 8) * h->cur_nimg; };
-                v = (tiles(18) <= 2.0 * ncu && tiles(19) <= 2.0 * ncu) ? 19 : 18;
-            }
+    static const std::vector<PlanVariant> geom = [] {
+        std::vector<PlanVariant> g;
+        for (const Variant& V : kVariants) g.push_back(PlanVariant{V.RI, V.RJ, V.tiles_per_block, V.min_image});
+        return g;
+    }();
+    PlanRequest q{h->M, h->N, h->cur_nimg, h->ncu, p.maxiter, p.tile_iters, p.reserved[0], p.reserved[1]};
+    const int rc = plan_pdhg(q, geom.data(), (int)geom.size(), pl);
+    switch (rc) {
+        case PLAN_OK: return BPLTV_OK;
+        case PLAN_E_VARIANT: return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", p.reserved[0]);
+        case PLAN_E_MIN_IMAGE: {
+            const Variant& V = kVariants[p.reserved[0] - 1];
+            return set_err(h, BPLTV_E_ARG, "kernel variant %d needs an image of at least %dx%d pixels", p.reserved[0], V.RI, V.RJ);
         }
+        case PLAN_E_TILE_ITERS: return set_err(h, BPLTV_E_ARG, "tile_iters must be >= 1");
+        case PLAN_E_GRID: return set_err(h, BPLTV_E_UNSUPPORTED, "%d problems of %dx%d pixels need more than 2^31 tiles per launch", h->cur_nimg, h->M, h->N);
+        default: return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", h->M, h->N, pl->T);
     }
-    if (v >= kNumVariants) return set_err(h, BPLTV_E_ARG, "unknown kernel variant %d", v + 1);
-    int T = p.tile_iters;
-    const bool auto_variant = p.reserved[0] <= 0;
-    if (T <= 0 && v == 0) {
-        // Region and fusion depth from a launch-cost model fitted on MI355X (round-1 sweeps):
-        // a launch costs a fixed ~4.5 us plus T iterations; an iteration of the 32x32 / 1 px kernel takes
-        // ~0.47 us while every CU holds at most one workgroup and ~0.94 us per round of two co-resident
-        // workgroups beyond that, one of the 48x48 / 3 px kernel 1.36 us resp. 2.1 us.  Deeper fusion means
-        // fewer launches but smaller cores, i.e. more (redundant) tiles; the larger region wastes fewer pixels on
-        // halos and wins once the batch no longer fits the chip with 32x32 regions (16 images of 128^2: -10 %,
-        // 32: -27 %).  Results do not depend on the choice.
-        // Round 3: the rows kernels (64x64 / 8 px: 1.95 us alone on a CU, 3.5 us per round of two; 64x48 / 6 px: 1.6 /
-        // 2.7 us; depth 8 only: their halo is one wave) join for images of at least one region -- they take over from
-        // about 16 images of 256^2 or 10 of 200^2 (+15-23 %), not for the 10 x 128^2 batch.
-        struct Cand { int v; double one, two; int tmin, tmax; };
-        const Cand cands[4] = {{0, 0.47, 0.94, 2, 12}, {12, 1.36, 2.1, 2, 12}, {18, 1.95, 3.5, 8, 8}, {19, 1.6, 2.7, 8, 8}};
-        double best = 1e300;
-        const int ncu = h->ncu > 0 ? h->ncu : 256;
-        for (const Cand& cd : cands) {
-            if (cd.v != 0 && !auto_variant) continue;
-            const Variant& Vc = kVariants[cd.v];
-            if (Vc.min_image && (M < Vc.RI || N < Vc.RJ)) continue;
-            for (int t = cd.tmin; t <= cd.tmax; ++t) {
-                if ((M > Vc.RI && 2 * t >= Vc.RI) || (N > Vc.RJ && 2 * t >= Vc.RJ)) continue;   // no core left
-                const int a = tile_count(M, Vc.RI, t), b = tile_count(N, Vc.RJ, t);
-                if (a < 1 || b < 1) continue;
-                const double tiles = (double)a * b * h->cur_nimg;
-                const double rounds = tiles / (2.0 * ncu);
-                // whole rounds for the short tile workgroups; the long rows workgroups overlap the tail of a round
-                const double eff = Vc.min_image ? (rounds <= 1.0 ? 1.0 : 0.5 * (std::ceil(rounds) + rounds)) : std::ceil(rounds);
-                const double per_iter = (tiles <= ncu) ? cd.one : cd.two * eff;
-                double cost = std::ceil((double)std::max(p.maxiter, 1) / t) * (4.5 + t * per_iter);
-                // two launch chains (below: from 1.5 workgroups per CU) hide part of every launch of the 32x32 kernel:
-                // 10 images at T = 8 and 5 images at T = 10 take 0.74 / 0.69 of what the single-chain model says
-                // (only within one round of workgroups: with several rounds every round pays its own prologue and state
-                //  round trip and the discount misleads -- 32 ... 64 images, 6 / 10 x 256^2 were 7-33 % slower with it; and
-                //  not for shallow fusion, where that per-round cost dominates: 4 x 256^2 at T = 4 was 13 % slower)
-                if (cd.v == 0 && p.reserved[1] != 1 && h->cur_nimg >= 2 && 2.0 * tiles > 3.0 * ncu && tiles <= 2.0 * ncu && t >= 6) cost *= 0.72;
-                if (cost < best) { best = cost; T = t; v = cd.v; }
-            }
-        }
-    }
-    if (kVariants[v].min_image && (M < kVariants[v].RI || N < kVariants[v].RJ)) {
-        if (!auto_variant)
-            return set_err(h, BPLTV_E_ARG, "kernel variant %d needs an image of at least %dx%d pixels", v + 1, kVariants[v].RI, kVariants[v].RJ);
-        v = 12;
-    }
-    const Variant& V = kVariants[v];
-    if (T <= 0) {
-        // Large images (round-1 sweep over 1 x 1024^2 ... 16 x 1024^2, 2 x 2048^2, 8 x 512^2): 48x48 regions
-        // of 3 px/thread beat the 64x64 / 4 px variant by 7-18 %; depth 8, or 6 once the grid is
-        // many times the chip (the smaller halo then saves more arithmetic than the extra launches cost).
-        T = 8;   // the rows kernels: one halo wave at each end of the region
-        if (v == 12 && (double)tile_count(M, V.RI, 8) * tile_count(N, V.RJ, 8) * h->cur_nimg > 8192.0) T = 6;
-    }
-    // the halo must leave a core when the image is larger than the region
-    auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
-    int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
-    if (T > cap) T = cap;
-    if (T < 1) return set_err(h, BPLTV_E_ARG, "tile_iters must be >= 1");
-    pl->variant = v;
-    pl->T = T;
-    pl->nTi = tile_count(M, V.RI, T);
-    pl->nTj = tile_count(N, V.RJ, T);
-    if (pl->nTi < 1 || pl->nTj < 1) return set_err(h, BPLTV_E_ARG, "cannot tile %dx%d with T=%d", M, N, T);
-    pl->grid = pl->nTi * pl->nTj * h->cur_nimg;
-    // Independent image groups ("chains") of the launch graph: images never exchange data, so
-    // their launch sequences may overlap (one chain's launch/memory latency hides behind another's
-    // arithmetic).  reserved[1]: 0 = auto, n = at most n chains.
-    int ch = p.reserved[1];
-    if (ch <= 0) {
-        // Two chains once the batch is well beyond one workgroup per CU: the second chain's kernels run in
-        // the first one's launch gaps (10 x 128^2: 7.2e5 -> 8.5e5 it/s; 8 / 32 / 64 images +18 / 26 / 16 %; the large-image
-        // workloads +2 %).  Smaller batches are faster as one chain (2-5 images: -3 ... -10 % with two).  Chain 0 runs on
-        // the handle's own stream, chain 1 on a second one: those two hardware queues overlap; a third does not (it shares
-        // a pipe with the second: 3 chains 7.8e5) -- DESIGN.md section 4.1.
-        const int ncu = h->ncu > 0 ? h->ncu : 256;
-        ch = (2 * pl->grid > 3 * ncu && h->cur_nimg >= 2) ? 2 : 1;   // from 1.5 workgroups per CU (6 / 7 images of 128^2: +1.5 / -8.5 % with two chains)
-    }
-    if (ch > h->cur_nimg) ch = h->cur_nimg;
-    pl->chains = ch;
-    return BPLTV_OK;
-}
-
-// May an odd launch chain run half a launch out of phase (first launch T/2 iterations, one launch more, starting in the
-// other state set)?  Only when that leaves it in the same final set as the even chains, and for long sequences.
-bool chain_out_of_phase(int niter, int T, bool from_state) {
-    const int nl0 = (niter + T - 1) / T, h0 = T / 2;
-    return !from_state && T >= 2 && nl0 >= 8 && ((1 + (niter - h0 + T - 1) / T) - nl0) % 2 == 1;
 }
 
 // Build one hipGraph per chain (image group): maxiter iterations as a linear launch sequence.

@@ -29,14 +29,9 @@
 #include <thread>
 #include <vector>
 
-namespace bpltv {
+#include "tiling.hpp"   // shard_range
 
-// Block distribution of O images over `world` shards: the first O % world shards get one more.
-inline void shard_range(int O, int world, int rank, int* lo, int* hi) {
-    const int base = O / world, rem = O % world;
-    *lo = rank * base + (rank < rem ? rank : rem);
-    *hi = *lo + base + (rank < rem ? 1 : 0);
-}
+namespace bpltv {
 
 // One persistent host thread per shard: it sets its device once and then runs the jobs the caller's thread
 // hands it.  run_all() posts one job per worker and waits for all of them, so the library is quiescent when

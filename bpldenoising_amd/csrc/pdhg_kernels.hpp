@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "tiling.hpp"   // tile_span, tile_count (host + device; also compiled by g++ under the sanitizers)
+
 namespace bpltv {
 
 // LDS bytes of pdhg_tile_kernel for a region RI x RJ: y1 plane with a guard column, y2 plane with a
@@ -81,36 +83,6 @@ struct PdhgArgs {
 __device__ __forceinline__ void pdhg_data_image(int img, int O, int Odata, int& fimg, int& apar) {
     if (O == Odata) { fimg = img; apar = 0; }        // no sweep: the solve images are the dataset's
     else { fimg = img % Odata; apar = img / Odata; }
-}
-
-// 1-D tiling with halo: region length R, halo T, image length L.  Tile a covers region
-// [o, o+R) and owns (writes back) the core [c0, c1).  Image borders need no halo (Neumann).
-__host__ __device__ inline void tile_span(int a, int L, int R, int T, int& o, int& c0, int& c1) {
-    if (L <= R) {
-        o = 0; c0 = 0; c1 = L;
-        return;
-    }
-    const int S = R - 2 * T;
-    const int cs = (a == 0) ? 0 : (R - T) + (a - 1) * S;
-    int oo = (a == 0) ? 0 : cs - T;
-    if (oo + R >= L) {
-        oo = L - R;
-        c1 = L;
-    } else {
-        c1 = oo + R - T;
-    }
-    o = oo;
-    c0 = cs;
-}
-
-inline int tile_count(int L, int R, int T) {
-    if (L <= R) return 1;
-    if (R - 2 * T < 1) return -1;
-    for (int a = 0;; ++a) {
-        int o, c0, c1;
-        tile_span(a, L, R, T, o, c0, c1);
-        if (c1 >= L) return a + 1;
-    }
 }
 
 __device__ __forceinline__ double alpha_at(const double* __restrict__ alpha, int am, int an, int M,

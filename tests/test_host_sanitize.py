@@ -1,0 +1,64 @@
+"""AddressSanitizer + UBSan over the library's host-only C++ (sanitizers row; GPU sanitizers are not
+available on this pool, so this is the CPU build): the symbolic phase of the nested dissection with its host
+restatement (csrc/nd_symbolic.hpp through tools/nd_host_check.cpp) and the tiling / sharding / planning arithmetic of
+the PDHG path (csrc/tiling.hpp through tools/plan_host_check.cpp -- the fuzz found the int overflow of the tile count
+that plan_pdhg now reports as PLAN_E_GRID)."""
+import os
+import subprocess
+import pytest
+from conftest import ROOT
+
+SAN = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+
+
+def _build(tmp_path, src, name):
+    exe = tmp_path / name
+    try:
+        subprocess.check_call(SAN + [os.path.join(ROOT, "tools", src), "-o", str(exe)])
+    except (subprocess.CalledProcessError, FileNotFoundError) as e:
+        pytest.skip("sanitizer build unavailable: %s" % e)
+    return str(exe)
+
+
+def _run(exe, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([exe] + list(args), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
+    return out.stdout
+
+
+def test_nested_dissection_symbolic_phase_under_asan_ubsan(tmp_path):
+    exe = _build(tmp_path, "nd_host_check.cpp", "nd_host_check_san")
+    assert "all ok" in _run(exe)
+    assert "bytes_per_image tv" in _run(exe, "bytes", "300", "48")      # an odd wide shape through the same code
+
+
+def test_tiling_sharding_and_planning_under_asan_ubsan(tmp_path):
+    exe = _build(tmp_path, "plan_host_check.cpp", "plan_host_check_san")
+    out = _run(exe, "150000")
+    assert out.startswith("all ok") and "0 failures" in out, out
+
+
+def test_plan_refuses_a_grid_beyond_int_range():
+    """What the fuzz found: K * O problems x tiles per image can exceed 2^31 workgroups; the planner says so instead of
+    overflowing (the library turns it into BPLTV_E_UNSUPPORTED)."""
+    src = r'''
+#include <cstdio>
+#include "bpldenoising_amd/csrc/tiling.hpp"
+int main() {
+    const bpltv::PlanVariant tab[1] = {{32, 32, 1, 0}};
+    bpltv::PlanRequest q{2100, 2100, 500000, 256, 100, 2, 1, 0};
+    bpltv::Plan pl{};
+    const int rc = bpltv::plan_pdhg(q, tab, 1, &pl);
+    printf("rc %d\n", rc);
+    return rc == bpltv::PLAN_E_GRID ? 0 : 1;
+}
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.cpp")
+        open(p, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++17", "-I", ROOT, p, "-o", exe])
+        assert subprocess.run([exe]).returncode == 0
