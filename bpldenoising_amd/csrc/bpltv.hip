@@ -89,6 +89,16 @@ void launch_rows_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       reinterpret_cast<const void*>(&pdhg_rows_kernel<double, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL),  \
       "rows_64x" #PJ "px_" #TJ "waves" #CL, &launch_rows_variant<float, PJ, TJ, CL>,            \
       reinterpret_cast<const void*>(&pdhg_rows_kernel<float, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL, sizeof(float)), 1, 1 }
+// the same re-cut for instruction-level parallelism (pdhg_rows2_kernel): G dual chains of an interior wave in flight
+template <typename T, int PJ, int TJ, int G>
+void launch_rows2_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pdhg_rows2_kernel<T, PJ, TJ, G>), pdhg_grid(a, grid), dim3(64 * TJ), pdhg_rows2_lds(PJ, TJ, sizeof(T)), s, a);
+}
+#define VARR2(PJ, TJ, G)                                                                        \
+    { 64, PJ * TJ, 64 * TJ, &launch_rows2_variant<double, PJ, TJ, G>,                           \
+      reinterpret_cast<const void*>(&pdhg_rows2_kernel<double, PJ, TJ, G>), pdhg_rows2_lds(PJ, TJ),  \
+      "rows2_64x" #PJ "px_" #TJ "waves_g" #G, &launch_rows2_variant<float, PJ, TJ, G>,          \
+      reinterpret_cast<const void*>(&pdhg_rows2_kernel<float, PJ, TJ, G>), pdhg_rows2_lds(PJ, TJ, sizeof(float)), 1, 1 }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
@@ -119,6 +129,11 @@ const Variant kVariants[] = {
     VARR(12, 8, true),  // 27: 64x96 region, 12 px per thread, 512 threads
     VARR(12, 4, true),  // 28: 64x48 region, 12 px per thread, 256 threads
     VARR(16, 4, true),  // 29: 64x64 region, 16 px per thread, 256 threads
+    VARR2(8, 8, 1),     // 30: rows2, 64x64 region, 8 px per thread; one dual chain at a time (the trims alone)
+    VARR2(8, 8, 2),     // 31: ... two dual chains in flight
+    // (round 4, 8 x 1024^2 pixel map, 480 iterations: variant 19 4.09-4.22e4 it/s, 30 4.09-4.15e4, 31 4.02e4, four chains
+    //  3.83e4 (spills); 64x48 / 6 px with two or three chains 3.51e4 against variant 20's 3.58e4 -- fewer moves and more
+    //  chains in flight buy nothing: DESIGN.md section 4.1)
     // (64x36 / 3 px and 64x48 / 4 px with 64-thread rows -- whole halo waves that stop early -- were measured too: 86
     //  resp. 110 VGPRs, one workgroup per CU, 1.88e4 / 2.14e4 it/s on 8 x 1024^2 against 2.55e4 for variant 13)
     // (64x48 / 3 px, 48x48 / 4 px, 56x54 / 3 px, 48x48 with the 3 px along i, 64x32 / 2 px were measured on
@@ -563,7 +578,8 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             std::memset(&kp, 0, sizeof(kp));
             kp.func = const_cast<void*>(h->dtype == 32 ? V.func32 : V.func);
             a.ntiles = tilesPerImg * (hi - lo);
-            a.grid3d = pdhg_grid3d_ok(pl.nTj, hi - lo, V.tiles_per_block);
+            a.xcd = (p.reserved[2] & 2) ? 1 : 0;
+            a.grid3d = a.xcd ? 0 : pdhg_grid3d_ok(pl.nTj, hi - lo, V.tiles_per_block);
             kp.gridDim = a.grid3d ? pdhg_grid(a, a.ntiles) : dim3((tilesPerImg * (hi - lo) + V.tiles_per_block - 1) / V.tiles_per_block);
             kp.blockDim = dim3(V.threads);
             kp.sharedMemBytes = (unsigned)(h->dtype == 32 ? V.lds32 : V.lds);
@@ -610,7 +626,8 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
     a.img0 = 0;
     a.ntiles = pl.grid;
-    a.grid3d = pdhg_grid3d_ok(pl.nTj, h->cur_nimg, V.tiles_per_block);
+    a.xcd = (p.reserved[2] & 2) ? 1 : 0;
+    a.grid3d = a.xcd ? 0 : pdhg_grid3d_ok(pl.nTj, h->cur_nimg, V.tiles_per_block);
 #ifdef BPLTV_EXPERIMENTS
     a.dbg = p.reserved[3];
 #endif
@@ -789,7 +806,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (!chunked) {
         bool done = main_iters == 0;
         if (p.use_graph && !done) {
-            GraphKey key{main_iters, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3], h->cur_nimg, (const void*)pdhg_state(h, 0, 0), (const void*)d_tab, from_state ? 1 : 0};
+            GraphKey key{main_iters, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3] | ((p.reserved[2] & 2) << 16), h->cur_nimg, (const void*)pdhg_state(h, 0, 0), (const void*)d_tab, from_state ? 1 : 0};
             auto it = h->graphs.find(key);
             const int nl = (main_iters + pl.T - 1) / pl.T;
             if (it == h->graphs.end() && h->graphs.size() >= 16) {  // bounded cache
@@ -806,7 +823,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
             }
             if (it != h->graphs.end()) {
                 const std::vector<hipGraphExec_t>& ex = it->second;
-                if (ex.size() == 1 || p.reserved[2] == 1) {
+                if (ex.size() == 1 || (p.reserved[2] & 1)) {
                     // reserved[2] = 1: replay the chains one after the other (no kernels in flight
                     // together) -- used by bench.py to time an isolated launch, as rocprofv3 sees it
                     for (size_t c = 0; c < ex.size(); ++c) HIPCHK(h, hipGraphLaunch(ex[c], h->stream));

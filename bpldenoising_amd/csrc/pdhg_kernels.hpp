@@ -55,9 +55,12 @@ struct PdhgArgs {
     int ntiles; // tiles of this launch (pdhg_wave_kernel: several tiles per workgroup, the last one may be short)
     int grid3d; // 1: the grid is (nTi, nTj, images): tile and image come from blockIdx.x / .y / .z and the kernel's prologue
                 // needs no integer division (4 of them, ~100 scalar instructions per wave, with the 1-D grid)
+    int xcd;    // 1 (1-D grid only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2; remap the
+                // linear workgroup index so that every XCD works on a contiguous run of tiles (neighbouring tiles re-read
+                // each other's halos: from the same L2 instead of from the memory side)
 #ifdef BPLTV_EXPERIMENTS
     int dbg;    // timing experiments of tools/ builds only (results are wrong): 1 skip state loads, 2 skip
-                // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads.  The product
+                // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads, 128 no barriers (rows kernel).  The product
                 // library is compiled without this field and without the branches it feeds.
 #endif
 };
@@ -76,8 +79,14 @@ struct PdhgArgs {
         ta = (int)blockIdx.x; tb = (int)blockIdx.y; imgl = (int)blockIdx.z;  \
     } else {                                                                 \
         const int tilesPerImg_ = (A).nTi * (A).nTj;                          \
-        imgl = (int)blockIdx.x / tilesPerImg_;                               \
-        const int t_ = (int)blockIdx.x - imgl * tilesPerImg_;                \
+        int lin_ = (int)blockIdx.x;                                          \
+        if ((A).xcd) {                                                       \
+            const int q_ = (int)gridDim.x >> 3, r_ = (int)gridDim.x & 7;     \
+            const int x_ = lin_ & 7, i_ = lin_ >> 3;                         \
+            lin_ = x_ * q_ + (x_ < r_ ? x_ : r_) + i_;                       \
+        }                                                                    \
+        imgl = lin_ / tilesPerImg_;                                          \
+        const int t_ = lin_ - imgl * tilesPerImg_;                           \
         ta = t_ % (A).nTi; tb = t_ / (A).nTi;                                \
     }
 __device__ __forceinline__ void pdhg_data_image(int img, int O, int Odata, int& fimg, int& apar) {
@@ -486,6 +495,16 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
     const int tid = threadIdx.x, ti = tid & 63;
     const int tj = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: uniform
     PDHG_DECODE_BLOCK(A, imgl, ta, tb)
+#ifdef BPLTV_EXPERIMENTS
+    if ((BPLTV_DBG(A) >> 8) > 0) {   // experiment: the initially resident workgroups start at pseudo-random phases
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < 512u) {
+            const unsigned hsh = (lin * 2654435761u) >> 16;
+            const int units = (int)(hsh % (unsigned)(BPLTV_DBG(A) >> 8));   // 1024 cycles each
+            for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
     const int img = A.img0 + imgl;
     int oi, ci0, ci1, oj, cj0, cj1;
     tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
     const size_t fbase = (size_t)fimg * M * N;
     const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
     const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
-    const bool first = A.first != 0;
+    const bool first = (A.first != 0) || (BPLTV_DBG(A) & 1);
     const int lj0 = PJ * tj;
     const int gi = min(oi + ti, M - 1);
     const bool in_i = oi + ti < M;
@@ -568,7 +587,7 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
             }
         }
         sxb[tj * 64 + ti] = xb[0];
-        __syncthreads();
+        if (!(BPLTV_DBG(A) & 128)) __syncthreads();
         // ---- dual step
         const T xbdn = sxb[(tj + 1) * 64 + ti];   // xbar of the pixel row below the strip
 #pragma unroll
@@ -599,14 +618,264 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
         }
         sy2[(tj + 1) * 64 + ti] = y2[PJ - 1];
         tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
+        if (!(BPLTV_DBG(A) & 128)) __syncthreads();
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gi2 = oi + ti, gj2 = oj + lj0 + pj;
+        if (gi2 >= ci0 && gi2 < ci1 && gj2 >= cj0 && gj2 < cj1 && !(BPLTV_DBG(A) & 2)) {
+            const size_t idx = base + gi2 + (size_t)M * gj2;
+            __hip_atomic_store(&Axout[idx], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pdhg_rows2_kernel: pdhg_rows_kernel re-cut for instruction-level parallelism (round 4).  Same layout (a wave = one row
+// of 64 lanes along i, PJ pixels per thread along j, DPP i-neighbours, strip ends through LDS, halo pixel rows that stop
+// early), same arithmetic per pixel (bit-identical), but:
+//   * interior waves (every pixel row runs all iterations -- 6 of the 8 waves of a 64 x 64 region, and every wave next
+//     to an image border) run straight-line code: the dual chains of G pixels are issued together -- projection as
+//     multiply by (outside ? alpha * rsqrt : 1.0), exact, instead of an exec-masked branch per pixel -- so that one
+//     workgroup alone keeps a SIMD's f64 pipe busy while its neighbour loads or stores (pdhg_rows_kernel: one 25-deep
+//     dependent chain per wave at a time);
+//   * f lives in LDS (own cells, read back once per iteration at the top of the primal step): 2 PJ registers freed for
+//     the interleaved chains;
+//   * x ping-pongs between two register sets over a loop unrolled by two (no copy of the new x per pixel), the lane shift
+//     for xbar(i+1) zero-fills lane 63 and the Neumann difference at the image's last column comes from a per-lane step
+//     sigma * {1, 0} instead (no two moves per pixel to seed the shift).
+// ------------------------------------------------------------------------------------------
+constexpr size_t pdhg_rows2_lds(int PJ, int TJ, size_t word = sizeof(double)) {
+    return word * 64 * (2 * (size_t)(TJ + 1) + 2 * (size_t)PJ * TJ);
+}
+__device__ __forceinline__ double pd_lane_next_or0(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float pd_lane_next_or0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+template <typename T, int PJ, int TJ, int G>
+__global__ __launch_bounds__(64 * TJ, TJ / 2) void pdhg_rows2_kernel(PdhgArgs A) {   // two workgroups per CU: 128 VGPRs
+    constexpr int RI = 64, RJ = PJ * TJ;
+    static_assert(PJ % G == 0, "pixel groups");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pdhg_smem[];
+    T* sy2 = reinterpret_cast<T*>(pdhg_smem);   // [TJ + 1][64]: row tj + 1 = y2 of strip tj's last pixel row, row 0 = 0
+    T* sxb = sy2 + (TJ + 1) * 64;               // [TJ + 1][64]: row tj = xbar of strip tj's first pixel row, row TJ = 0
+    T* sf = sxb + (TJ + 1) * 64;                // [RJ][64]: f, every thread its own cells
+    T* sal = sf + RJ * 64;                      // [RJ][64]: alpha, likewise
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
+    const int tid = threadIdx.x, ti = tid & 63;
+    const int tj = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: uniform
+    PDHG_DECODE_BLOCK(A, imgl, ta, tb)
+    const int img = A.img0 + imgl;
+    int oi, ci0, ci1, oj, cj0, cj1;
+    tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
+    tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
+    const int M = A.M, N = A.N;
+    int fimg, apar;
+    pdhg_data_image(img, A.O, A.Odata, fimg, apar);
+    const size_t base = (size_t)img * M * N;
+    const size_t fbase = (size_t)fimg * M * N;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const bool first = A.first != 0;
+    const int lj0 = PJ * tj;
+    const int gi = min(oi + ti, M - 1);
+    const bool in_i = oi + ti < M;
+
+    T xa[PJ], xc[PJ], y1[PJ], y2[PJ];
+    {
+        T f[PJ], al[PJ];
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            const int gj = min(oj + lj0 + pj, N - 1);
+            const size_t gidx = gi + (size_t)M * gj;
+            size_t ai = 0;
+            if (amode == 2) ai = gidx;
+            else if (amode == 1) ai = ((unsigned)gi * (unsigned)A.am) / (unsigned)M + (size_t)A.am * (((unsigned)gj * (unsigned)A.an) / (unsigned)N);
+            if (!first) {
+                xa[pj] = Axin[base + gidx];
+                y1[pj] = Ay1in[base + gidx];
+                y2[pj] = Ay2in[base + gidx];
+            }
+            f[pj] = Af[fbase + gidx];
+            al[pj] = alpha[ai];
+        }
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            if (first) { xa[pj] = f[pj]; y1[pj] = T(0); y2[pj] = T(0); }
+            if (!(in_i && oj + lj0 + pj < N)) { f[pj] = T(0); xa[pj] = T(0); y1[pj] = T(0); y2[pj] = T(0); al[pj] = T(0); }
+            sf[(lj0 + pj) * 64 + ti] = f[pj];
+            sal[(lj0 + pj) * 64 + ti] = al[pj];
+        }
+    }
+    sy2[(tj + 1) * 64 + ti] = y2[PJ - 1];
+    if (tj == 0) { sy2[ti] = T(0); sxb[TJ * 64 + ti] = T(0); }
+    __syncthreads();
+
+    const T rho = (T)A.rho;
+    const int nit = A.nit;
+    const bool hasD_last = oj + lj0 + PJ - 1 < N - 1;
+    // the image's last column is lane 63 of the last region (images are at least a region wide): its forward difference
+    // along i is +0.  The lane shift delivers 0 there; sigma * 0 keeps y1 = +0 exactly as xbar - xbar = +0 does.
+    const T m1 = (ti == 63 && oi + 63 >= M - 1) ? T(0) : T(1);
+    // iterations pixel row lj is still read for (see pdhg_rows_kernel)
+    int lim[PJ];
+    int lim_min = nit;
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int lj = lj0 + pj;
+        int l = nit;
+        if (oj > 0) l = min(l, lj);
+        if (oj + RJ < N) l = min(l, RJ - lj);
+        lim[pj] = l;
+        lim_min = min(lim_min, l);
+    }
+    const bool interior = lim_min >= nit;   // wave-uniform
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
+
+    // one iteration: x from xi to xo
+    auto iterate = [&](const T (&xi)[PJ], T (&xo)[PJ], int it) {
+        const T tau = row[TAB_STRIDE * it + 0], sigma = row[TAB_STRIDE * it + 1], omega = row[TAB_STRIDE * it + 2],
+                inv1ptau = row[TAB_STRIDE * it + 3], opw = row[TAB_STRIDE * it + 4];
+        const T sig1 = sigma * m1;
+        T xb[PJ];
+        const T y2up = sy2[tj * 64 + ti];   // y2 of the pixel row above the strip (guard row of zeros at lj = 0)
+        if (interior) {
+#pragma unroll
+            for (int g0 = 0; g0 < PJ; g0 += G) {
+                T fv[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) fv[g] = sf[(lj0 + g0 + g) * 64 + ti];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int pj = g0 + g;
+                    const T y1m = pd_lane_prev_or0(y1[pj]);
+                    const T y2m = (pj > 0) ? y2[pj > 0 ? pj - 1 : 0] : y2up;
+                    const T div = (y1m - y1[pj]) + (y2m - y2[pj]);
+                    const T tt = div - fv[g];
+                    const T xn = pd_fma(-tau, tt, xi[pj]) * inv1ptau;
+                    xb[pj] = pd_fma(-omega, xi[pj], opw * xn);
+                    xo[pj] = xn;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) {
+                xb[pj] = T(0);
+                xo[pj] = xi[pj];
+                if (it < lim[pj]) {
+                    const T y1m = pd_lane_prev_or0(y1[pj]);
+                    const T y2m = (pj > 0) ? y2[pj > 0 ? pj - 1 : 0] : y2up;
+                    const T div = (y1m - y1[pj]) + (y2m - y2[pj]);
+                    const T tt = div - sf[(lj0 + pj) * 64 + ti];
+                    const T xn = pd_fma(-tau, tt, xi[pj]) * inv1ptau;
+                    xb[pj] = pd_fma(-omega, xi[pj], opw * xn);
+                    xo[pj] = xn;
+                }
+            }
+        }
+        sxb[tj * 64 + ti] = xb[0];
         __syncthreads();
+        const T xbdn = sxb[(tj + 1) * 64 + ti];   // xbar of the pixel row below the strip
+        if (interior) {
+#pragma unroll
+            for (int g0 = 0; g0 < PJ; g0 += G) {
+                T n2v[G], av[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) av[g] = sal[(lj0 + g0 + g) * 64 + ti];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int pj = g0 + g;
+                    const T b = xb[pj];
+                    const T xp1 = pd_lane_next_or0(b);
+                    const T xpM = (pj < PJ - 1) ? xb[pj < PJ - 1 ? pj + 1 : pj] : (hasD_last ? xbdn : b);
+                    const T d1 = xp1 - b;
+                    const T d2 = xpM - b;
+                    T y1n = pd_fma(sig1, d1, y1[pj]);
+                    T y2n = pd_fma(sigma, d2, y2[pj]);
+                    if (rho != T(0)) {
+                        const T den = T(1) + sigma * rho / av[g];
+                        y1n = y1n / den;
+                        y2n = y2n / den;
+                    }
+                    y1[pj] = y1n;
+                    y2[pj] = y2n;
+                    n2v[g] = pd_fma(y2n, y2n, y1n * y1n);
+                }
+                bool any_out = false;
+#pragma unroll
+                for (int g = 0; g < G; ++g) any_out |= n2v[g] > av[g] * av[g];
+                if (any_out) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int pj = g0 + g;
+                        const T a = av[g];
+                        const T v = (n2v[g] > a * a) ? a * rsqrt_nr(n2v[g]) : T(1);   // y * 1 = y exactly
+                        y1[pj] = y1[pj] * v;
+                        y2[pj] = y2[pj] * v;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: G chains in flight, not PJ
+            }
+        } else {
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) {
+                if (it < lim[pj]) {
+                    const T b = xb[pj];
+                    const T xp1 = pd_lane_next_or0(b);
+                    const T xpM = (pj < PJ - 1) ? xb[pj < PJ - 1 ? pj + 1 : pj] : (hasD_last ? xbdn : b);
+                    const T d1 = xp1 - b;
+                    const T d2 = xpM - b;
+                    const T a = sal[(lj0 + pj) * 64 + ti];
+                    T y1n = pd_fma(sig1, d1, y1[pj]);
+                    T y2n = pd_fma(sigma, d2, y2[pj]);
+                    if (rho != T(0)) {
+                        const T den = T(1) + sigma * rho / a;
+                        y1n = y1n / den;
+                        y2n = y2n / den;
+                    }
+                    const T n2v = pd_fma(y2n, y2n, y1n * y1n);
+                    if (n2v > a * a) {
+                        const T v = a * rsqrt_nr(n2v);
+                        y1n = y1n * v;
+                        y2n = y2n * v;
+                    }
+                    y1[pj] = y1n;
+                    y2[pj] = y2n;
+                }
+            }
+        }
+        sy2[(tj + 1) * 64 + ti] = y2[PJ - 1];
+        __syncthreads();
+    };
+    int it = 0;
+    for (; it + 1 < nit; it += 2) {
+        iterate(xa, xc, it);
+        iterate(xc, xa, it + 1);
+    }
+    if (it < nit) {
+        iterate(xa, xc, it);
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) xa[pj] = xc[pj];
     }
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj) {
         const int gi2 = oi + ti, gj2 = oj + lj0 + pj;
         if (gi2 >= ci0 && gi2 < ci1 && gj2 >= cj0 && gj2 < cj1) {
             const size_t idx = base + gi2 + (size_t)M * gj2;
-            __hip_atomic_store(&Axout[idx], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Axout[idx], xa[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -113,6 +113,7 @@ class TVSolver:
         variant = kw.pop("variant", None)
         chains = kw.pop("chains", None)
         serialize = kw.pop("serialize_chains", None)
+        xcd = kw.pop("xcd", None)
         adjm = kw.pop("adjoint_method", None)
         for k, v in kw.items():
             if k in _IGNORED:
@@ -128,6 +129,8 @@ class TVSolver:
             p.reserved[1] = int(chains)    # independent launch chains in the hipGraph, 0 = auto
         if serialize is not None:
             p.reserved[2] = int(bool(serialize))  # replay launch chains one after the other (timing aid)
+        if xcd is not None:
+            p.reserved[2] |= 2 * int(xcd)        # 1: XCD-aware tile order, 2: natural order (0 = by image size)
         if adjm is not None:
             p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2, "nd": 3}.get(adjm, adjm)  # adjoint factorisation
         return p
