@@ -148,3 +148,24 @@ function sumregs_learning_function(x::Union{AbstractVector{Float64},AbstractArra
         h.ptr, a, am, an, Δ, p, u, cost, grad))
     return u, cost[], grad
 end
+
+# generate_cost / generate_2d_cost, src/BPLDenoising.jl:92-111,136-158: cost(alpha_k) = L2CostFunction(TVDenoise(f, alpha_k), true)
+# for K parameters (a Vector of scalars, or an m x n x K array of parameter matrices) as ONE bpltv_sweep call.  Over several
+# GPUs (BPLTV_NGPUS) the library splits the images or -- a one-image dataset, the default num_samples = 1 of :313 -- the K
+# parameter blocks over replicas of the dataset; the costs are bitwise those of one GPU.
+function generate_cost_sweep(data, parameters; maxiter = 10000)
+    ū, f = data[1], data[2]
+    h = handle_for(ū, f)
+    a = Array{Float64}(parameters)
+    am, an, K = ndims(a) == 1 ? (1, 1, length(a)) : (size(a, 1), size(a, 2), size(a, 3))
+    costs = zeros(K)
+    p = Ref(default_params(; maxiter = maxiter))
+    GC.@preserve a costs bpltv_check(h, ccall((:bpltv_sweep, libbpltv), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint, Cint, Ref{BpltvParams}, Ptr{Cdouble}, Ptr{Cdouble}),
+        h.ptr, a, K, am, an, p, costs, C_NULL))
+    return costs
+end
+
+# test / measurement aids of a handle (include/bpltv.h, bpltv_set_option), e.g. set_option(h, "sweep_split", 2)
+set_option(h::BpltvHandle, name::String, value::Real) =
+    bpltv_check(h, ccall((:bpltv_set_option, libbpltv), Cint, (Ptr{Cvoid}, Cstring, Cdouble), h.ptr, name, value))
