@@ -358,6 +358,24 @@ def extra_workload(TVSolver, torch, name, O, size, iters, steps, alpha_map, eval
     return out
 
 
+def outer_loop_extra():
+    """The unit the reference's user waits for: one whole run of the outer trust-region loop (bilevel_learn,
+    /root/reference/src/TRBox.jl:192-273, driven as scalar_bilevel_tv_learn does, /root/reference/src/BPLDenoising.jl:316-336)
+    on faces_train_128_10 through the reference-named entry point -- host arrays in, (u, cost, grad) out per evaluation,
+    i.e. the PCIe-inclusive drop-in path: every evaluation is 5000 PDHG iterations + loss + adjoint gradient of 10 images."""
+    import bpldenoising_amd as B
+    ub, f, label = load_batch("faces_train_128_10", 10, 128, 128, 20211004)
+    B.learning_function.clear_cache()
+    t0 = time.perf_counter()
+    x, u, hist = B.trbox.bilevel_learn((ub, f), B.tv_op_learning_function, 0.1, 0.1, maxiter=20)
+    dt = time.perf_counter() - t0
+    B.learning_function.clear_cache()
+    return {"workload": "bilevel_learn (TRBox, scalar alpha, alpha0 = 0.1, Delta0 = 0.1, maxiter 20, tol 1e-5) on %s, 10 images; "
+                        "host arrays through tv_op_learning_function (PCIe inclusive)" % label,
+            "wall_s": dt, "evaluations": len(hist) + 1, "ms_per_evaluation": 1e3 * dt / (len(hist) + 1),
+            "learned_alpha": float(x), "final_cost": float(hist[-1]["function_value"]) if hist else None}
+
+
 def sweep_bench(args, TVSolver, shard_range, torch):
     """`--sweep K`: generate_cost of /root/reference/src/BPLDenoising.jl:92-111 -- K parameters x the images of a dataset,
     TVDenoise each -- as ONE bpltv_sweep through a handle over --gpus devices.  The reference's default is ONE image
@@ -697,6 +715,7 @@ def main():
                 out["extra_workloads"] = {
                     "single_image": extra_workload(TVSolver, torch, "single_image", 1, 128, args.iters, 5, False, True, "faces_train_128_10"),
                     "config5_share": extra_workload(TVSolver, torch, "config5_share", 8, 1024, 2000, 3, True, True, "synthetic", eval_iters=400),
+                    "outer_loop": outer_loop_extra(),
                 }
             except Exception as e:   # never lose the headline line to an extra
                 out["extra_workloads"] = {"error": "%s: %s" % (type(e).__name__, e)}

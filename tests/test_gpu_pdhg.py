@@ -362,3 +362,44 @@ def test_run_time_choices_are_rejected_where_unsupported(gpu_solver_cls):
         s.sumregs_denoise(np.array([0.03, 0.02, 0.05]), maxiter=5, init=1)
     assert e.value.code == 6
     s.close()
+
+
+def test_parameter_resident_in_hbm_and_handle_options(gpu_solver_cls):
+    """bpltv_denoise_device: the parameter map handed over as a device pointer (checked on the device: finite, >= 0), the
+    result left in HBM -- the same bits as bpltv_denoise from host arrays.  bpltv_set_option: unknown names and bad
+    values are BPLTV_E_ARG."""
+    import torch
+    from bpldenoising_amd._lib import BpltvError
+    O, N, M = 2, 96, 80
+    ub, f = synth_batch(O, N, M, seed=51)
+    amap = 0.03 + 0.15 * np.random.default_rng(7).random((N, M))
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u0 = s.denoise(amap, maxiter=77)
+    t_a = torch.from_numpy(amap).cuda()
+    out = torch.empty(O * N * M, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    s.denoise_device(t_a.data_ptr(), M, N, maxiter=77)
+    s.copy_u_device(out.data_ptr())
+    assert np.array_equal(out.cpu().numpy().reshape(O, N, M), u0)
+    t_s = torch.tensor([0.09], dtype=torch.float64, device="cuda")          # a scalar parameter the same way
+    s.denoise_device(t_s.data_ptr(), 1, 1, maxiter=40)
+    s.copy_u_device(out.data_ptr())
+    assert np.array_equal(out.cpu().numpy().reshape(O, N, M), s.denoise(0.09, maxiter=40))
+    for bad in (-0.1, float("nan"), float("inf")):
+        t_b = t_a.clone(); t_b[3, 5] = bad
+        torch.cuda.synchronize()
+        with pytest.raises(BpltvError) as e:
+            s.denoise_device(t_b.data_ptr(), M, N, maxiter=5)
+        assert e.value.code == 1 and "finite" in str(e.value)
+    for name, val in (("no_such_option", 1), ("hb_sync", 7), ("hb_rw", 64), ("adjoint_budget_mb", -1), ("nd_leaf", 99999)):
+        with pytest.raises(BpltvError) as e:
+            s.set_option(name, val)
+        assert e.value.code == 1, name
+    s.set_option("nd_leaf", 16)                                              # another elimination tree, the same gradient
+    _, _, g16 = s.evaluate(0.1, 0.1, maxiter=150)
+    s.set_option("nd_leaf", 0)
+    _, _, g32 = s.evaluate(0.1, 0.1, maxiter=150)
+    assert np.isclose(g16, g32, rtol=1e-7)
+    s.close()
+
