@@ -368,11 +368,14 @@ def outer_loop_extra():
     B.learning_function.clear_cache()
     t0 = time.perf_counter()
     x, u, hist = B.trbox.bilevel_learn((ub, f), B.tv_op_learning_function, 0.1, 0.1, maxiter=20)
-    dt = time.perf_counter() - t0
+    dt_first = time.perf_counter() - t0          # with the one-time costs: handle, dataset upload, adjoint workspace, elimination tree, graphs
+    t0 = time.perf_counter()
+    x, u, hist = B.trbox.bilevel_learn((ub, f), B.tv_op_learning_function, 0.1, 0.1, maxiter=20)
+    dt = time.perf_counter() - t0                # the same run again on the cached handle
     B.learning_function.clear_cache()
     return {"workload": "bilevel_learn (TRBox, scalar alpha, alpha0 = 0.1, Delta0 = 0.1, maxiter 20, tol 1e-5) on %s, 10 images; "
                         "host arrays through tv_op_learning_function (PCIe inclusive)" % label,
-            "wall_s": dt, "evaluations": len(hist) + 1, "ms_per_evaluation": 1e3 * dt / (len(hist) + 1),
+            "wall_s": dt, "first_run_wall_s": dt_first, "evaluations": len(hist) + 1, "ms_per_evaluation": 1e3 * dt / (len(hist) + 1),
             "learned_alpha": float(x), "final_cost": float(hist[-1]["function_value"]) if hist else None}
 
 
