@@ -46,7 +46,8 @@ struct Variant {
     const void* func32;
     size_t lds32;
     int tiles_per_block;   // 1: one workgroup per tile (pdhg_tile_kernel); > 1: that many one-wave tiles per workgroup
-    int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel)
+    int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel); 2: at least as wide
+    int tmax = 0;          // > 0: most iterations a launch can fuse (pdhg_stream_kernel)
 };
 
 // grid of a launch of `tiles` tiles: (nTi, nTj, images) when the kernel decodes blockIdx that way (PdhgArgs::grid3d)
@@ -99,6 +100,16 @@ void launch_rows2_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       reinterpret_cast<const void*>(&pdhg_rows2_kernel<double, PJ, TJ, G>), pdhg_rows2_lds(PJ, TJ),  \
       "rows2_64x" #PJ "px_" #TJ "waves_g" #G, &launch_rows2_variant<float, PJ, TJ, G>,          \
       reinterpret_cast<const void*>(&pdhg_rows2_kernel<float, PJ, TJ, G>), pdhg_rows2_lds(PJ, TJ, sizeof(float)), 1, 1 }
+// a pipeline of waves streaming down a 64-column strip (pdhg_stream_kernel): SEG rows per segment core, NL levels
+template <typename T, int NL, int D, int FD, int PF, int WPE>
+void launch_stream_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pdhg_stream_kernel<T, NL, D, FD, PF, WPE>), pdhg_grid(a, grid), dim3(64 * NL), (pdhg_stream_lds<NL, D, FD>(sizeof(T))), s, a);
+}
+#define VARS(SEG, NL, D, FD, PF, WPE)                                                               \
+    { 64, SEG + 2 * NL, 64 * NL, &launch_stream_variant<double, NL, D, FD, PF, WPE>,                  \
+      reinterpret_cast<const void*>(&pdhg_stream_kernel<double, NL, D, FD, PF, WPE>), pdhg_stream_lds<NL, D, FD>(),  \
+      "stream_64x" #SEG "rows_" #NL "levels_d" #D, &launch_stream_variant<float, NL, D, FD, PF, WPE>, \
+      reinterpret_cast<const void*>(&pdhg_stream_kernel<float, NL, D, FD, PF, WPE>), pdhg_stream_lds<NL, D, FD>(sizeof(float)), 1, 2, NL }
 const Variant kVariants[] = {
     VAR(1, 1, 32, 32),  // 1: 32x32 region, 1 px/thread   (small images, shallow blocking)
     VAR(2, 2, 32, 32),  // 2: 64x64 region, 4 px/thread
@@ -131,6 +142,11 @@ const Variant kVariants[] = {
     VARR(16, 4, true),  // 29: 64x64 region, 16 px per thread, 256 threads
     VARR2(8, 8, 1),     // 30: rows2, 64x64 region, 8 px per thread; one dual chain at a time (the trims alone)
     VARR2(8, 8, 2),     // 31: ... two dual chains in flight
+    VARS(256, 8, 4, 32, 2, 4),   // 32: streaming pipeline of 8 waves, segments of 256 rows, rings of 4 rows (76 KB of LDS), 128 VGPRs: two workgroups per CU
+    VARS(256, 8, 2, 16, 2, 6),   // 33: ... rings of 2 rows (38 KB), 80 VGPRs: three workgroups per CU
+    // (round 4, 8 x 1024^2 pixel map, 480 iterations: 32 / 33 run 2.9-3.0e4 / 3.2-3.3e4 it/s against 4.1-4.2e4 of variant 19; four or
+    //  six rows of prefetch (spills) 3.0e4; segments of 128 / 352 / 512 rows 3.2e4 / 3.0e4 / 2.2e4; the same pipeline fed by a
+    //  loader wave through LDS-DMA 2.2-3.3e4 -- DESIGN.md section 4.1)
     // (round 4, 8 x 1024^2 pixel map, 480 iterations: variant 19 4.09-4.22e4 it/s, 30 4.09-4.15e4, 31 4.02e4, four chains
     //  3.83e4 (spills); 64x48 / 6 px with two or three chains 3.51e4 against variant 20's 3.58e4 -- fewer moves and more
     //  chains in flight buy nothing: DESIGN.md section 4.1)
@@ -517,7 +533,7 @@ int upload_alpha_device(bpltv_t* h, const double* d_alpha, int am, int an) {
 int make_plan(bpltv_t* h, const bpltv_params& p, Plan* pl) {
     static const std::vector<PlanVariant> geom = [] {
         std::vector<PlanVariant> g;
-        for (const Variant& V : kVariants) g.push_back(PlanVariant{V.RI, V.RJ, V.tiles_per_block, V.min_image});
+        for (const Variant& V : kVariants) g.push_back(PlanVariant{V.RI, V.RJ, V.tiles_per_block, V.min_image, V.tmax});
         return g;
     }();
     PlanRequest q{h->M, h->N, h->cur_nimg, h->ncu, p.maxiter, p.tile_iters, p.reserved[0], p.reserved[1]};
@@ -562,7 +578,7 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             a.am = h->last_am; a.an = h->last_an;
             a.M = h->M; a.N = h->N; a.O = h->cur_nimg;
             a.Odata = h->O; a.astride = h->cur_astride;
-            a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
+            a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T; a.seg = V.RJ;
             a.img0 = lo;
 #ifdef BPLTV_EXPERIMENTS
             a.dbg = p.reserved[3];
@@ -623,7 +639,7 @@ int enqueue_pdhg(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
     a.an = h->last_an;
     a.M = h->M; a.N = h->N; a.O = h->cur_nimg;
     a.Odata = h->O; a.astride = h->cur_astride;
-    a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T;
+    a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T; a.seg = V.RJ;
     a.img0 = 0;
     a.ntiles = pl.grid;
     a.xcd = (p.reserved[2] & 2) ? 1 : 0;

@@ -55,6 +55,7 @@ struct PdhgArgs {
     int ntiles; // tiles of this launch (pdhg_wave_kernel: several tiles per workgroup, the last one may be short)
     int grid3d; // 1: the grid is (nTi, nTj, images): tile and image come from blockIdx.x / .y / .z and the kernel's prologue
                 // needs no integer division (4 of them, ~100 scalar instructions per wave, with the 1-D grid)
+    int seg;    // pdhg_stream_kernel: rows of a segment's region (core + the lead-in rows at its artificial ends)
     int xcd;    // 1 (1-D grid only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2; remap the
                 // linear workgroup index so that every XCD works on a contiguous run of tiles (neighbouring tiles re-read
                 // each other's halos: from the same L2 instead of from the memory side)
@@ -878,6 +879,214 @@ __global__ __launch_bounds__(64 * TJ, TJ / 2) void pdhg_rows2_kernel(PdhgArgs A)
             __hip_atomic_store(&Axout[idx], xa[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pdhg_stream_kernel: the T fused iterations as a PIPELINE OF WAVES that streams down the image (round 4).
+//
+// pdhg_rows_kernel loads a 64 x 64 region, iterates T times behind workgroup barriers and stores the core: its memory
+// phases and its compute phase overlap only through the second workgroup of the CU, and the halo rows above and below the
+// core are recomputed.  Here a workgroup owns a strip of 64 columns (lanes along i, halo T on each side that is not an
+// image border, exactly as the rows kernel) and a segment of rows, and wave t (t = 1 .. nit) computes ITERATION t of the
+// launch for one pixel row after the other:
+//     wave 1 reads row r of the input state from HBM (prefetched PF rows ahead) and hands f(r), alpha(r) to everyone,
+//     wave t reads row r of level t - 1 from an LDS ring, does the primal step of row r and -- one row behind, because the
+//     dual step needs xbar of the row below -- the dual step of row r - 1, and hands row r - 1 of level t to wave t + 1,
+//     wave nit stores its rows to HBM.
+// Waves synchronise pairwise through two counters per level in LDS (rows produced, rows consumed): no workgroup barrier in
+// the loop, loads, arithmetic and stores of a workgroup run all the time, and along j nothing is recomputed but the nit
+// lead-in rows at each artificial end of a segment (the rows kernel: T halo rows of every 64).  Neighbours along i are the
+// adjacent lanes (DPP), neighbours along j are the wave's own previous row (registers) and the next row of the level
+// below (the ring).  Same arithmetic per pixel as every other variant: bit-identical results.
+// Validity: a value of level t is wrong within t lanes of a strip edge that is not an image border (never stored: the
+// core starts T >= nit lanes in) and within t rows of a segment end that is not an image border (never stored: a segment's
+// region is its core plus T rows at each such end, tile_span).
+// grid (strips, segments, images), block 64 * NL; images at least 64 pixels wide.
+// ------------------------------------------------------------------------------------------
+template <int NL, int D, int FD>
+constexpr size_t pdhg_stream_lds(size_t word = sizeof(double)) {
+    return word * 64 * ((size_t)(NL - 1) * D * 3 + (size_t)FD * 2) + sizeof(int) * 2 * (NL + 2);
+}
+__device__ __forceinline__ void pd_wait_ge(int* p, int v) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void pd_publish(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <typename T, int NL, int D, int FD, int PF, int WPE>
+__global__ __launch_bounds__(64 * NL, WPE) void pdhg_stream_kernel(PdhgArgs A) {   // WPE: waves per SIMD the register budget allows
+    static_assert((FD & (FD - 1)) == 0 && (D & (D - 1)) == 0, "ring depths: powers of two");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pdhg_smem[];
+    T* ring = reinterpret_cast<T*>(pdhg_smem);            // [NL - 1][D][3][64]: output rows of levels 1 .. NL - 1
+    T* fa = ring + (size_t)(NL - 1) * D * 3 * 64;         // [FD][2][64]: f and alpha rows
+    int* prod = reinterpret_cast<int*>(fa + (size_t)FD * 2 * 64);   // prod[t]: rows level t has produced (t = 0: f / alpha rows)
+    int* cons = prod + (NL + 2);                          // cons[t]: input rows wave t has consumed (read out of the ring below it)
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
+    const int tid = threadIdx.x, ti = tid & 63;
+    const int lev = __builtin_amdgcn_readfirstlane(tid >> 6) + 1;   // this wave's level: 1 .. NL (uniform)
+    if (tid < 2 * (NL + 2)) prod[tid] = 0;
+    __syncthreads();                                               // the only workgroup barrier
+    const int nit = A.nit;
+    if (lev > nit) return;                                         // a short last launch: the upper levels have nothing to do
+    PDHG_DECODE_BLOCK(A, imgl, ta, tb)
+    const int img = A.img0 + imgl;
+    const int M = A.M, N = A.N;
+    int oi, ci0, ci1, rs, cj0, cj1;
+    tile_span(ta, M, 64, A.halo, oi, ci0, ci1);
+    tile_span(tb, N, A.seg, A.halo, rs, cj0, cj1);                 // rows [rs, re) are processed, [cj0, cj1) are stored
+    const int re = min(N, rs + A.seg);
+    int fimg, apar;
+    pdhg_data_image(img, A.O, A.Odata, fimg, apar);
+    const size_t base = (size_t)img * M * N + (size_t)(oi + ti);
+    const size_t fbase = (size_t)fimg * M * N + (size_t)(oi + ti);
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const unsigned pa = (amode == 1) ? ((unsigned)(oi + ti) * (unsigned)A.am) / (unsigned)M : 0u;
+    const bool first = A.first != 0;
+    const bool last = lev == nit;                                  // this wave stores to HBM
+    const bool core_i = (oi + ti >= ci0) && (oi + ti < ci1);
+    const T rho = (T)A.rho;
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * (A.it0 + lev - 1);
+    const T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    // the image's last column is lane 63 of the last strip: its forward difference along i is +0 (see pdhg_rows2_kernel)
+    const T sig1 = sigma * ((ti == 63 && oi + 63 >= M - 1) ? T(0) : T(1));
+    T* myring = ring + (size_t)(lev - 1) * D * 3 * 64;             // where this level's rows go (lev < nit)
+    const T* inring = ring + (size_t)(lev - 2) * D * 3 * 64;       // where its input rows come from (lev > 1)
+    const int nrows = re - rs;
+
+    // level 1: its input rows come from HBM, PF rows in flight
+    T pX[PF], pY1[PF], pY2[PF], pF[PF], pA[PF];
+    auto fetch = [&](int q, int slot) {                            // row rs + q of the launch's input
+        const int r = min(rs + q, N - 1);
+        const size_t o = (size_t)M * r;
+        pF[slot] = Af[fbase + o];
+        if (!first) { pX[slot] = Axin[base + o]; pY1[slot] = Ay1in[base + o]; pY2[slot] = Ay2in[base + o]; }
+        T a;
+        if (amode == 0) a = alpha[0];
+        else if (amode == 2) a = alpha[(size_t)(oi + ti) + o];
+        else a = alpha[pa + (size_t)A.am * (((unsigned)r * (unsigned)A.an) / (unsigned)N)];
+        pA[slot] = a;
+    };
+    if (lev == 1) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(u, u);
+    }
+    T Y1p = T(0), Y2p = T(0), XBp = T(0), Xnp = T(0), Ap = T(0);   // of the previous row: y of the level below, xbar and x of this level, alpha
+    // one row step; q = row index within the region, slot = q % PF (static)
+    auto step = [&](int q, int slot) {
+        T X, Y1, Y2, Fv, Av;
+        if (lev == 1) {
+            Fv = pF[slot]; Av = pA[slot];
+            if (first) { X = Fv; Y1 = T(0); Y2 = T(0); }
+            else { X = pX[slot]; Y1 = pY1[slot]; Y2 = pY2[slot]; }
+            if (q + PF < nrows) fetch(q + PF, slot);
+            if (nit > 1) {                                         // f and alpha of this row for the levels above
+                if (q >= FD) pd_wait_ge(&cons[nit], q - FD + 1);   // the slot's previous row has been used by the last level
+                fa[((q & (FD - 1)) * 2 + 0) * 64 + ti] = Fv;
+                fa[((q & (FD - 1)) * 2 + 1) * 64 + ti] = Av;
+                pd_publish(&prod[0], q + 1);
+            }
+        } else {
+            pd_wait_ge(&prod[lev - 1], q + 1);                     // row q of the level below is in its ring
+            const T* src = inring + (size_t)(q & (D - 1)) * 3 * 64;
+            X = src[ti]; Y1 = src[64 + ti]; Y2 = src[128 + ti];
+            Fv = fa[((q & (FD - 1)) * 2 + 0) * 64 + ti];           // (prod[0] > q follows: level 1 wrote it before its row q)
+            Av = fa[((q & (FD - 1)) * 2 + 1) * 64 + ti];
+            pd_publish(&cons[lev], q + 1);
+        }
+        // ---- primal step of row q
+        const T y1m = pd_lane_prev_or0(Y1);
+        const T y2m = (q > 0 || rs > 0) ? Y2p : T(0);              // row above; the image's first row has the zero guard
+        const T div = (y1m - Y1) + (y2m - Y2);
+        const T tt = div - Fv;
+        const T xn = pd_fma(-tau, tt, X) * inv1ptau;
+        const T xb = pd_fma(-omega, X, opw * xn);
+        // ---- dual step of row q - 1 (needs xbar of row q)
+        if (q > 0) {
+            const T b = XBp;
+            const T xp1 = pd_lane_next_or0(b);
+            const T d1 = xp1 - b;
+            const T d2 = xb - b;
+            T y1n = pd_fma(sig1, d1, Y1p);
+            T y2n = pd_fma(sigma, d2, Y2p);
+            if (rho != T(0)) {
+                const T den = T(1) + sigma * rho / Ap;
+                y1n = y1n / den;
+                y2n = y2n / den;
+            }
+            const T n2v = pd_fma(y2n, y2n, y1n * y1n);
+            if (n2v > Ap * Ap) {
+                const T v = Ap * rsqrt_nr(n2v);
+                y1n = y1n * v;
+                y2n = y2n * v;
+            }
+            const int qo = q - 1;                                  // the finished row of this level
+            if (last) {
+                const int gj = rs + qo;
+                if (core_i && gj >= cj0 && gj < cj1) {
+                    const size_t idx = base + (size_t)M * gj;
+                    __hip_atomic_store(&Axout[idx], Xnp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Ay1out[idx], y1n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&Ay2out[idx], y2n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (qo >= D) pd_wait_ge(&cons[lev + 1], qo - D + 1);   // the slot's previous row has been read
+                T* dst = myring + (size_t)(qo & (D - 1)) * 3 * 64;
+                dst[ti] = Xnp; dst[64 + ti] = y1n; dst[128 + ti] = y2n;
+                pd_publish(&prod[lev], qo + 1);
+            }
+        }
+        Y1p = Y1; Y2p = Y2; XBp = xb; Xnp = xn; Ap = Av;
+    };
+    int q = 0;
+    for (; q + PF <= nrows; q += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(q + u, u);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (q + u < nrows) step(q + u, u);
+    // the dual step of the last row: below it is the image's border (forward difference +0) or an artificial segment
+    // end (the row is invalid and not stored; any finite value will do)
+    {
+        const T b = XBp;
+        const T xp1 = pd_lane_next_or0(b);
+        const T d1 = xp1 - b;
+        const T d2 = b - b;
+        T y1n = pd_fma(sig1, d1, Y1p);
+        T y2n = pd_fma(sigma, d2, Y2p);
+        if (rho != T(0)) {
+            const T den = T(1) + sigma * rho / Ap;
+            y1n = y1n / den;
+            y2n = y2n / den;
+        }
+        const T n2v = pd_fma(y2n, y2n, y1n * y1n);
+        if (n2v > Ap * Ap) {
+            const T v = Ap * rsqrt_nr(n2v);
+            y1n = y1n * v;
+            y2n = y2n * v;
+        }
+        const int qo = nrows - 1;
+        if (last) {
+            const int gj = rs + qo;
+            if (core_i && gj >= cj0 && gj < cj1) {
+                const size_t idx = base + (size_t)M * gj;
+                __hip_atomic_store(&Axout[idx], Xnp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&Ay1out[idx], y1n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&Ay2out[idx], y2n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (qo >= D) pd_wait_ge(&cons[lev + 1], qo - D + 1);
+            T* dst = myring + (size_t)(qo & (D - 1)) * 3 * 64;
+            dst[ti] = Xnp; dst[64 + ti] = y1n; dst[128 + ti] = y2n;
+            pd_publish(&prod[lev], qo + 1);
         }
     }
 }

@@ -66,8 +66,14 @@ inline bool chain_out_of_phase(int niter, int T, bool from_state) {
 struct PlanVariant {
     int RI, RJ;            // region (core + halo) of one workgroup / tile
     int tiles_per_block;   // > 1: several one-wave tiles per workgroup (pdhg_wave_kernel)
-    int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel)
+    int min_image;         // 1: the image must be at least as large as the region (pdhg_rows_kernel); 2: at least as wide (M >= RI,
+                           // pdhg_stream_kernel: its region along j is a segment of rows, any image height); 3: and M even
+                           // (pdhg_stream2_kernel: its loader moves pairs of pixels, 16-byte pieces)
+    int tmax;              // > 0: most iterations one launch can fuse (pdhg_stream_kernel: one wave per iteration)
 };
+inline bool plan_too_small(const PlanVariant& V, int M, int N) {
+    return (V.min_image == 1 && (M < V.RI || N < V.RJ)) || (V.min_image >= 2 && M < V.RI) || (V.min_image == 3 && (M & 1));
+}
 struct PlanRequest {
     int M, N, nimg;        // image size, images of the solve (K * O for a sweep)
     int ncu;               // compute units of the device (0: 256)
@@ -121,7 +127,7 @@ inline int plan_pdhg(const PlanRequest& q, const PlanVariant* tab, int ntab, Pla
             if (cd.v != PLAN_V_TILE32 && !auto_variant) continue;
             if (cd.v >= ntab) continue;
             const PlanVariant& Vc = tab[cd.v];
-            if (Vc.min_image && (M < Vc.RI || N < Vc.RJ)) continue;
+            if (plan_too_small(Vc, M, N)) continue;
             for (int t = cd.tmin; t <= cd.tmax; ++t) {
                 if ((M > Vc.RI && 2 * t >= Vc.RI) || (N > Vc.RJ && 2 * t >= Vc.RJ)) continue;   // no core left
                 const int a = tile_count(M, Vc.RI, t), b = tile_count(N, Vc.RJ, t);
@@ -140,7 +146,7 @@ inline int plan_pdhg(const PlanRequest& q, const PlanVariant* tab, int ntab, Pla
             }
         }
     }
-    if (tab[v].min_image && (M < tab[v].RI || N < tab[v].RJ)) {
+    if (plan_too_small(tab[v], M, N)) {
         if (!auto_variant) return PLAN_E_MIN_IMAGE;
         v = PLAN_V_TILE48;
     }
@@ -153,7 +159,8 @@ inline int plan_pdhg(const PlanRequest& q, const PlanVariant* tab, int ntab, Pla
     }
     // the halo must leave a core when the image is larger than the region
     auto maxT = [](int L, int R) { return (L <= R) ? (1 << 20) : (R - 1) / 2; };
-    const int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
+    int cap = std::min(maxT(M, V.RI), maxT(N, V.RJ));
+    if (V.tmax > 0) cap = std::min(cap, V.tmax);
     if (T > cap) T = cap;
     if (T < 1) return PLAN_E_TILE_ITERS;
     pl->variant = v;

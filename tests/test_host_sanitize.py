@@ -47,7 +47,7 @@ def test_plan_refuses_a_grid_beyond_int_range():
 #include <cstdio>
 #include "bpldenoising_amd/csrc/tiling.hpp"
 int main() {
-    const bpltv::PlanVariant tab[1] = {{32, 32, 1, 0}};
+    const bpltv::PlanVariant tab[1] = {{32, 32, 1, 0, 0}};
     bpltv::PlanRequest q{2100, 2100, 500000, 256, 100, 2, 1, 0};
     bpltv::Plan pl{};
     const int rc = bpltv::plan_pdhg(q, tab, 1, &pl);

@@ -65,10 +65,10 @@ static void check_tiling(int L, int R, int T) {
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 200000;
     // the variant geometries of csrc/bpltv.hip (region RI x RJ, tiles per workgroup, needs an image of a region)
-    const PlanVariant tab[] = {{32, 32, 1, 0}, {64, 64, 1, 0}, {16, 16, 1, 0}, {32, 32, 1, 0}, {64, 32, 1, 0}, {64, 64, 1, 0}, {64, 16, 1, 0},
-                               {128, 16, 1, 0}, {128, 32, 1, 0}, {32, 64, 1, 0}, {40, 40, 1, 0}, {40, 40, 1, 0}, {48, 48, 1, 0}, {96, 64, 1, 0},
-                               {96, 48, 1, 0}, {32, 32, 4, 0}, {32, 16, 4, 0}, {32, 24, 4, 0}, {64, 64, 1, 1}, {64, 48, 1, 1}, {64, 128, 1, 1},
-                               {64, 64, 1, 1}, {64, 96, 1, 1}, {64, 64, 1, 1}, {64, 48, 1, 1}, {64, 80, 1, 1}, {64, 96, 1, 1}, {64, 48, 1, 1}, {64, 64, 1, 1}};
+    const PlanVariant tab[] = {{32, 32, 1, 0, 0}, {64, 64, 1, 0, 0}, {16, 16, 1, 0, 0}, {32, 32, 1, 0, 0}, {64, 32, 1, 0, 0}, {64, 64, 1, 0, 0}, {64, 16, 1, 0, 0},
+                               {128, 16, 1, 0, 0}, {128, 32, 1, 0, 0}, {32, 64, 1, 0, 0}, {40, 40, 1, 0, 0}, {40, 40, 1, 0, 0}, {48, 48, 1, 0, 0}, {96, 64, 1, 0, 0},
+                               {96, 48, 1, 0, 0}, {32, 32, 4, 0, 0}, {32, 16, 4, 0, 0}, {32, 24, 4, 0, 0}, {64, 64, 1, 1, 0}, {64, 48, 1, 1, 0}, {64, 128, 1, 1, 0},
+                               {64, 64, 1, 1, 0}, {64, 96, 1, 1, 0}, {64, 64, 1, 1, 0}, {64, 48, 1, 1, 0}, {64, 80, 1, 1, 0}, {64, 96, 1, 1, 0}, {64, 48, 1, 1, 0}, {64, 64, 1, 1, 0}, {64, 272, 1, 2, 8}, {64, 144, 1, 2, 8}};
     const int ntab = (int)(sizeof(tab) / sizeof(tab[0]));
     // edge shapes first, then random ones
     for (int L : {1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 4096})
@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
         const int rc = plan_pdhg(q, tab, ntab, &pl);
         if (rc != PLAN_OK) {
             CHECK(rc == PLAN_E_VARIANT ? q.variant > ntab
-                                       : (rc == PLAN_E_MIN_IMAGE ? (q.variant >= 1 && tab[q.variant - 1].min_image && (q.M < tab[q.variant - 1].RI || q.N < tab[q.variant - 1].RJ))
+                                       : (rc == PLAN_E_MIN_IMAGE ? (q.variant >= 1 && plan_too_small(tab[q.variant - 1], q.M, q.N))
                                                                  : (rc == PLAN_E_GRID ? true : true)),
                   "plan rc %d for M %d N %d variant %d", rc, q.M, q.N, q.variant);
             continue;
@@ -111,7 +111,8 @@ int main(int argc, char** argv) {
         ++nplans;
         const PlanVariant& V = tab[pl.variant];
         CHECK(pl.variant >= 0 && pl.variant < ntab && pl.T >= 1, "plan variant %d T %d", pl.variant, pl.T);
-        CHECK(!(V.min_image && (q.M < V.RI || q.N < V.RJ)), "rows variant %d on a %dx%d image", pl.variant + 1, q.M, q.N);
+        CHECK(!plan_too_small(V, q.M, q.N), "rows variant %d on a %dx%d image", pl.variant + 1, q.M, q.N);
+        CHECK(V.tmax == 0 || pl.T <= V.tmax, "variant %d fuses %d > %d iterations", pl.variant + 1, pl.T, V.tmax);
         CHECK(q.M <= V.RI || V.RI - 2 * pl.T >= 1, "no core along i: M %d R %d T %d", q.M, V.RI, pl.T);
         CHECK(q.N <= V.RJ || V.RJ - 2 * pl.T >= 1, "no core along j: N %d R %d T %d", q.N, V.RJ, pl.T);
         CHECK(pl.nTi == tile_count(q.M, V.RI, pl.T) && pl.nTj == tile_count(q.N, V.RJ, pl.T) && pl.nTi >= 1 && pl.nTj >= 1, "tile counts %d x %d", pl.nTi, pl.nTj);
