@@ -252,6 +252,7 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
 // 1; zero where neither reaches), through the parent -> child maps `inv`.  No zero pass, no read-modify-write, no
 // atomics; nd_orig_kernel adds the few matrix entries afterwards.  A wave per front column, lanes down the rows: the
 // maps are monotone, so a wave reads runs of consecutive child entries.  grid (blocks, nodes, nimg), block 256.
+constexpr int NDG_U = 8;
 __global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
     const int node = A.node0 + blockIdx.y, img = blockIdx.z;
     const NdNodeDev v = A.nodes[node];
@@ -271,10 +272,10 @@ __global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
         double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
         const double* s0 = c0 >= 0 ? U0 + (size_t)b0 * c0 : nullptr;
         const double* s1 = c1 >= 0 ? U1 + (size_t)b1 * c1 : nullptr;
-        for (int R0 = C; R0 < f; R0 += 256) {      // four row chunks in flight per lane
-            double x[4];
+        for (int R0 = C; R0 < f; R0 += 64 * NDG_U) {   // NDG_U row chunks in flight per lane (index, then value: two dependent round trips each)
+            double x[NDG_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NDG_U; ++u) {
                 const int R = R0 + lane + 64 * u;
                 double acc = 0.0;
                 if (R < f) {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
                 x[u] = acc;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NDG_U; ++u) {
                 const int R = R0 + lane + 64 * u;
                 if (R < f) dst[R] = x[u];
             }
