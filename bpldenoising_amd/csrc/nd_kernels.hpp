@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "adjoint_hbm_kernels.hpp"
 
 namespace bpltv {
@@ -241,6 +243,208 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
     double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
     for (int j = wave; j < b; j += NW)
         for (int i = j + lane; i < b; i += 64) U[i + (size_t)b * j] = S[(p16 + i) + ld * (p16 + j)];
+    ND_PROBE(5);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// small regime, one WAVE per front: f <= F <= 64 rows (one per lane), p <= P <= 32 pivots
+// ------------------------------------------------------------------------------------------------------------------
+// The bottom levels of the tree are hundreds of thousands of fronts of a few dozen rows; nd_front_small_kernel spends
+// its time between workgroup barriers with one wave of two or four working.  Here a front belongs to ONE wave and, once
+// assembled, lives in registers: lane r holds row r, register j column j (lower triangle, a[j] of lane r = F(r, j)).
+// Right-looking elimination, step k: the scaled column l = F(:, k) / sqrt(d) is replicated into every row of 16 lanes
+// (ds_bpermute), and column j receives a[j] -= l * l_j with l_j taken by the DPP row broadcast of v_fmac_f64 -- one
+// VALU instruction per entry, no SGPR round trip (tools/dpp_probe.hip: 1.17 x a plain v_fmac_f64).  W = L11^-1 rides
+// along: L = Lt D (Lt unit lower, D = diag l_kk), X = Lt^-1 is built by the same row operations on the identity, held
+// TRANSPOSED (lane c, register r = X(r, c)) so that its multipliers lt_r = l_r / l_kk are the same kind of broadcast
+// and the pivot row X(k, :) is the lane's own register; W(k, :) = X(k, :) / l_kk is final after step k - 1.
+// Register indices are static: column k and row k are picked by a switch over k (P cases), whole blocks of eight
+// columns left of k or right of f are skipped by wave-uniform branches.  W and L21 are staged in LDS in the layout
+// of the factor (f x p, leading dimension f) and leave as one linear copy; U goes out of the registers column by column.
+// LDS: the packed lower triangle of the front while it is assembled (targets are data dependent), then the staging area.
+__device__ __forceinline__ int nd_tri(int F, int r, int c) { return r + ((c * (2 * F - 1 - c)) >> 1); }   // r >= c
+
+template <int N>
+__device__ __forceinline__ void nd_fmac_bc(double& acc, double src, double mul) {   // acc += src[lane 16 * (lane / 16) + N] * mul
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
+template <int J0, int NA, int NR, int... I>
+__device__ __forceinline__ void nd_fmac_block(double (&a)[NA], const double (&rep)[NR], double mul, std::integer_sequence<int, I...>) {
+    (nd_fmac_bc<(J0 + I) & 15>(a[J0 + I], rep[(J0 + I) >> 4], mul), ...);
+}
+// blocks lo <= jb < hi of eight registers each (lo, hi wave-uniform)
+template <int NA, int NR, int... JB>
+__device__ __forceinline__ void nd_fmac_blocks(double (&a)[NA], const double (&rep)[NR], double mul, int lo, int hi, std::integer_sequence<int, JB...>) {
+    ((JB >= lo && JB < hi ? nd_fmac_block<8 * JB>(a, rep, mul, std::make_integer_sequence<int, 8>()) : (void)0), ...);
+}
+__device__ __forceinline__ double nd_bperm_f64(int addr, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int P, int NA, int NX>
+__device__ __forceinline__ void nd_pick(const double (&a)[NA], const double (&xt)[NX], int k, double& ak, double& xk) {
+    // a branch per case (the empty asm keeps the compiler from turning the cases into 2 P selects)
+    switch (k) {
+        default: ak = a[0]; xk = xt[0]; asm volatile("" : "+v"(ak), "+v"(xk)); break;
+#define ND_PICK_CASE(c) case c: if (c < P) { ak = a[c < NA ? c : 0]; xk = xt[c < NX ? c : 0]; asm volatile("" : "+v"(ak), "+v"(xk)); } break;
+        ND_PICK_CASE(1) ND_PICK_CASE(2) ND_PICK_CASE(3) ND_PICK_CASE(4) ND_PICK_CASE(5) ND_PICK_CASE(6) ND_PICK_CASE(7)
+        ND_PICK_CASE(8) ND_PICK_CASE(9) ND_PICK_CASE(10) ND_PICK_CASE(11) ND_PICK_CASE(12) ND_PICK_CASE(13) ND_PICK_CASE(14) ND_PICK_CASE(15)
+        ND_PICK_CASE(16) ND_PICK_CASE(17) ND_PICK_CASE(18) ND_PICK_CASE(19) ND_PICK_CASE(20) ND_PICK_CASE(21) ND_PICK_CASE(22) ND_PICK_CASE(23)
+        ND_PICK_CASE(24) ND_PICK_CASE(25) ND_PICK_CASE(26) ND_PICK_CASE(27) ND_PICK_CASE(28) ND_PICK_CASE(29) ND_PICK_CASE(30) ND_PICK_CASE(31)
+#undef ND_PICK_CASE
+    }
+}
+
+template <int F, int P>
+constexpr int nd_wave_lds_doubles() { return (F * (F + 1) / 2 > F * P ? F * (F + 1) / 2 : F * P) + 2; }
+
+// grid (fronts of the level, nimg), block 64.  Fronts with f <= F and p <= P only (the host picks the instance per level).
+// Every global load of the assembly is requested before the first one is consumed (matrix-entry list, both children's
+// maps and the first NDW_U x 64 entries of each update matrix); the pivot of step k + 1 is brought up to date and its
+// rsqrt chain started while the replicated column of step k is still on its way through the LDS crossbar.
+constexpr int NDW_U = 16;   // update-matrix entries in flight per lane and child
+template <int F, int P>
+__global__ __launch_bounds__(64) void nd_front_wave_kernel(NdArgs A) {
+    static_assert(F % 8 == 0 && F <= 64 && P % 8 == 0 && P <= 32 && P <= F, "one row per lane, pivots picked by a 32-way switch");
+    constexpr int NQ = (F + 15) / 16, NQX = (P + 15) / 16, TRI = F * (F + 1) / 2;
+    __shared__ __attribute__((aligned(16))) double S[nd_wave_lds_doubles<F, P>()];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    ND_PROBE(0);
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    // requests: matrix-entry list (first four per lane), children's descriptors, maps and update matrices
+    int4 o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = lane + 64 * u;
+        o[u] = e < v.orig_cnt ? A.orig[v.orig_off + e] : make_int4(0, 0, 0, 0);
+    }
+    NdNodeDev ch[2];
+    int bc[2] = {0, 0}, cmv[2] = {0, 0};
+    const double* Uc[2] = {nullptr, nullptr};
+    double x[2][NDW_U];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn >= 0) { ch[ci] = A.nodes[cn]; bc[ci] = ch[ci].b; }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int n = bc[ci], nn = n * n;
+        if (n > 0) {
+            Uc[ci] = A.ws_child + (size_t)img * A.ws_child_stride + ch[ci].u_off;
+            cmv[ci] = lane < n ? A.cmap[ch[ci].cmap_off + lane] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < NDW_U; ++u) {
+            const int e = 64 * u + lane;
+            x[ci][u] = e < nn ? Uc[ci][e] : 0.0;
+        }
+    }
+    const double* pl = A.planes + (size_t)img * A.n;
+    double ov[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ov[u] = lane + 64 * u < v.orig_cnt ? pl[(size_t)(o[u].z & 15) * A.tot + o[u].w] : 0.0;
+    for (int e = 2 * lane; e < TRI; e += 128) *reinterpret_cast<double2*>(S + e) = make_double2(0.0, 0.0);
+    ND_PROBE(1);
+    // matrix entries of this front (unique targets, lower triangle: the front is ordered by elimination index)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < v.orig_cnt) S[nd_tri(F, o[u].x, o[u].y)] += ov[u];
+    for (int e = lane + 256; e < v.orig_cnt; e += 64) {
+        const int4 oo = A.orig[v.orig_off + e];
+        S[nd_tri(F, oo.x, oo.y)] += pl[(size_t)(oo.z & 15) * A.tot + oo.w];
+    }
+    ND_PROBE(2);
+    // the children's update matrices, read linearly (b x b, lower triangle valid), scattered through cmap: child 0, then
+    // child 1, each entry of a child to its own target -- the order of the additions is that of nd_front_small_kernel
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int n = bc[ci], nn = n * n;
+        if (n == 0) continue;
+        const unsigned magic = 0xFFFFFFFFu / (unsigned)n + 1u;     // e / n = umulhi(e, magic) for e < 2^16, n <= 64
+        for (int e0 = 0; e0 < nn; e0 += 64 * NDW_U) {
+            if (e0 > 0) {
+#pragma unroll
+                for (int u = 0; u < NDW_U; ++u) {
+                    const int e = e0 + 64 * u + lane;
+                    x[ci][u] = e < nn ? Uc[ci][e] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NDW_U; ++u) {
+                if (e0 + 64 * u >= nn) break;
+                const int e = min(e0 + 64 * u + lane, nn - 1);
+                const int j = (int)__umulhi((unsigned)e, magic), i = e - j * n;
+                const int row = __builtin_amdgcn_ds_bpermute(i << 2, cmv[ci]), col = __builtin_amdgcn_ds_bpermute(j << 2, cmv[ci]);
+                if (e0 + 64 * u + lane < nn && i >= j) S[nd_tri(F, row, col)] += x[ci][u];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a[F], xt[P];
+#pragma unroll
+    for (int j = 0; j < F; ++j) a[j] = (lane >= j && lane < F) ? S[lane + ((j * (2 * F - 1 - j)) >> 1)] : 0.0;
+#pragma unroll
+    for (int r = 0; r < P; ++r) xt[r] = lane == r ? 1.0 : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // the triangle is in registers: S becomes the staging area
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ND_PROBE(3);
+    const int bpa = (lane & 15) << 2;
+    const int jhi = (f + 7) >> 3, rhi = (p + 7) >> 3;
+    bool bad = false;
+    double ak = a[0], xk = xt[0], y = 1.0, sq;
+    if (p > 0) {
+        const double d = readlane_f64(ak, 0);
+        if (!(d > 0.0)) bad = true;
+        sqrt_rsqrt(d, sq, y);
+    }
+    for (int k = 0; k < p; ++k) {
+        const double l = ak * y;
+        const double lz = lane > k ? l : 0.0;
+        if (lane >= p && lane < f) S[lane + f * k] = l;          // L21(:, k)
+        if (lane < p) S[k + f * lane] = xk * y;                  // W(k, :), zero right of the diagonal
+        double rep[NQ], rept[NQX];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rep[q] = nd_bperm_f64(bpa + (q << 6), lz);
+        double nl = -lz, nxk = -xk;
+        // step k + 1's pivot column and pivot row of X, brought up to date here (the same fused operations the blocks
+        // below apply to a[k + 1] and xt[k + 1]) so that its rsqrt chain runs beside the broadcasts and the block updates
+        double ak1 = 0.0, xk1 = 0.0, y1 = 1.0;
+        if (k + 1 < p) {
+            nd_pick<P>(a, xt, k + 1, ak1, xk1);
+            const double l1 = readlane_f64(lz, k + 1);
+            ak1 = __builtin_fma(l1, nl, ak1);
+            xk1 = __builtin_fma(l1 * y, nxk, xk1);
+            const double d1 = readlane_f64(ak1, k + 1);
+            if (!(d1 > 0.0)) bad = true;
+            sqrt_rsqrt(d1, sq, y1);
+        }
+#pragma unroll
+        for (int q = 0; q < NQX; ++q) rept[q] = rep[q] * y;
+        // a VALU result read through DPP needs two wait states; the asm below is opaque to the hazard recogniser
+        if constexpr (NQX == 1) asm volatile("s_nop 1" : "+v"(rept[0]), "+v"(nl), "+v"(nxk));
+        else asm volatile("s_nop 1" : "+v"(rept[0]), "+v"(rept[1]), "+v"(nl), "+v"(nxk));
+        const int lo = (k + 1) >> 3;
+        nd_fmac_blocks(a, rep, nl, lo, jhi, std::make_integer_sequence<int, F / 8>());
+        nd_fmac_blocks(xt, rept, nxk, lo, rhi, std::make_integer_sequence<int, P / 8>());
+        ak = ak1; xk = xk1; y = y1;
+    }
+    ND_PROBE(4);
+    if (bad && lane == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    for (int e = lane; e < f * p; e += 64) fc[e] = S[e];
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+#pragma unroll
+    for (int j = 0; j < F; ++j)
+        if (j >= p && j < f && lane >= j && lane < f) U[(lane - p) + b * (j - p)] = a[j];
     ND_PROBE(5);
 }
 

@@ -31,6 +31,7 @@ struct NdSolver {
         int pmax = 0, bmax = 0, fmax = 0, MPmax = 0, bcmax = 0;   // bcmax: largest child boundary
         bool has_child = false;
         long long fac0 = 0, fac_len = 0, ws_len = 0;
+        int wave = -1;                 // >= 0: instance of nd_front_wave_kernel (a wave per front) that holds every front of the level
     };
     std::vector<Level> lv;
     bool built = false;
@@ -44,6 +45,26 @@ struct NdSolver {
     hipStream_t stream = nullptr;
     std::string err;
     double factor_flop = 0.0;          // per image (multiply-add = 2)
+    bool wave_fronts = true;           // Cholesky, fronts of <= 64 rows and <= 32 pivots: nd_front_wave_kernel (false: tools, A/B timing)
+
+    // the instances of nd_front_wave_kernel<F, P>, smallest first within a pivot class
+    struct WaveInst { int F, P; void (*fn)(NdArgs); };
+    static const WaveInst* wave_insts(int& n) {
+        static const WaveInst tab[] = {
+            {40, 8, nd_front_wave_kernel<40, 8>},   {56, 8, nd_front_wave_kernel<56, 8>},   {64, 8, nd_front_wave_kernel<64, 8>},
+            {24, 16, nd_front_wave_kernel<24, 16>}, {32, 16, nd_front_wave_kernel<32, 16>}, {48, 16, nd_front_wave_kernel<48, 16>},
+            {64, 16, nd_front_wave_kernel<64, 16>}, {48, 32, nd_front_wave_kernel<48, 32>}, {64, 32, nd_front_wave_kernel<64, 32>},
+        };
+        n = (int)(sizeof(tab) / sizeof(tab[0]));
+        return tab;
+    }
+    static int pick_wave(int fmax, int pmax) {
+        int n;
+        const WaveInst* t = wave_insts(n);
+        for (int i = 0; i < n; ++i)
+            if (t[i].F >= fmax && t[i].P >= pmax) return i;
+        return -1;
+    }
 
 #define NDCHK(call)                                                                               \
     do {                                                                                          \
@@ -89,6 +110,7 @@ struct NdSolver {
             // in LDS only while the pivot block is at most three block columns wide: wave 0 factors them one after the
             // other there; wider pivot blocks (the root of a 128-wide image) go through bcr_potrf_lds_body (large regime)
             a.small = a.MPmax <= 128 && a.pmax <= 48;
+            if (a.small && !lu) a.wave = pick_wave(a.fmax, a.pmax);
         }
         std::vector<NdNodeDev> nd(T.nodes.size());
         for (size_t q = 0; q < T.nodes.size(); ++q) {
@@ -202,7 +224,10 @@ struct NdSolver {
             const int cnt = a.n1 - a.n0;
             if (a.small) {
                 A.node0 = a.n0;
-                if (a.MPmax <= 48) hipLaunchKernelGGL((nd_front_small_kernel<false, 128>), dim3(cnt, nimg), dim3(128), nd_small_lds(a.MPmax), stream, A);
+                if (wave_fronts && a.wave >= 0) {
+                    int n;
+                    hipLaunchKernelGGL(wave_insts(n)[a.wave].fn, dim3(cnt, nimg), dim3(64), 0, stream, A);
+                } else if (a.MPmax <= 48) hipLaunchKernelGGL((nd_front_small_kernel<false, 128>), dim3(cnt, nimg), dim3(128), nd_small_lds(a.MPmax), stream, A);
                 else if (a.MPmax <= 64) hipLaunchKernelGGL((nd_front_small_kernel<false, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 else hipLaunchKernelGGL((nd_front_small_kernel<true, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 continue;

@@ -403,5 +403,9 @@ def test_parameter_resident_in_hbm_and_handle_options(gpu_solver_cls):
     s.set_option("nd_leaf", 0)
     _, _, g32 = s.evaluate(0.1, 0.1, maxiter=150)
     assert np.isclose(g16, g32, rtol=1e-7)
+    s.set_option("nd_wave", 0)                                               # small fronts by the workgroup-per-front kernel
+    _, _, gwg = s.evaluate(0.1, 0.1, maxiter=150)
+    s.set_option("nd_wave", 1)
+    assert np.isclose(gwg, g32, rtol=1e-9) and s.evaluate(0.1, 0.1, maxiter=150)[2] == g32
     s.close()
 

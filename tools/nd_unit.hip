@@ -202,6 +202,12 @@ static int timing(int M, int nimg, bool sr, int leaf) {
     const NdStencil st = sr ? nd_stencil_sr() : nd_stencil_tv();
     auto t0 = std::chrono::steady_clock::now();
     if (S.build(M, M, st, leaf)) { printf("build failed: %s\n", S.err.c_str()); return 1; }
+    if (getenv("ND_NO_WAVE")) S.wave_fronts = false;    // A/B: the workgroup-per-front kernel on every small level (this tool only)
+    {
+        int nw = 0, ns = 0;
+        for (const auto& a : S.lv) { ns += a.small; nw += a.small && S.wave_fronts && a.wave >= 0; }
+        printf("small levels %d, of them a wave per front %d\n", ns, nw);
+    }
     const double tb = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
