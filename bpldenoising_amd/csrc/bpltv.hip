@@ -12,6 +12,7 @@
 #include <initializer_list>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -195,6 +196,62 @@ struct SrGraphKey {
 
 struct MultiState;   // shards, worker threads and the RCCL communicator of a multi-device handle (below)
 
+// The streams of a device, shared by all its handles.  HIP maps streams onto a few hardware queues (four by default) as they
+// are created; with a stream pair per handle, the two launch chains of a second handle's solve can land on ONE queue and
+// run one after the other -- measured: the 5000-iteration denoise of the reference batch 5.8 -> 11.1 ms on a handle
+// created while another one is alive (the reference's workflow: a training set and a validation set), back to 6.0 ms with
+// GPU_MAX_HW_QUEUES=8.  So the first handle of a device creates the main stream and the chain streams back to back
+// (neighbouring queues), later handles reuse them, the last one to go destroys them.  The library is quiescent when an ABI
+// call returns, so handles used one after the other never meet on a stream; handles driven from several host threads at
+// once are ordered by the streams they share (each keeps its own events).
+struct DeviceStreams {
+    hipStream_t main = nullptr;
+    std::vector<hipStream_t> chains;
+    int refs = 0;
+};
+static std::mutex g_streams_mu;
+static std::map<int, DeviceStreams> g_streams;
+
+static hipError_t device_streams_acquire(int device, hipStream_t* main) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    DeviceStreams& ds = g_streams[device];
+    if (ds.refs == 0) {
+        hipError_t e = hipStreamCreateWithFlags(&ds.main, hipStreamNonBlocking);
+        if (e != hipSuccess) { ds.main = nullptr; return e; }
+        hipStream_t cs = nullptr;
+        e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);      // the second launch chain, next to the main stream
+        if (e != hipSuccess) { (void)hipStreamDestroy(ds.main); ds.main = nullptr; return e; }
+        ds.chains.push_back(cs);
+    }
+    ++ds.refs;
+    *main = ds.main;
+    return hipSuccess;
+}
+// chain stream c (0-based) of the device, created on first use
+static hipError_t device_streams_chain(int device, size_t c, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    DeviceStreams& ds = g_streams[device];
+    while (ds.chains.size() <= c) {
+        hipStream_t cs = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        ds.chains.push_back(cs);
+    }
+    *out = ds.chains[c];
+    return hipSuccess;
+}
+static void device_streams_release(int device) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    auto it = g_streams.find(device);
+    if (it == g_streams.end() || it->second.refs <= 0) return;
+    if (--it->second.refs == 0) {
+        for (auto cs : it->second.chains) (void)hipStreamDestroy(cs);
+        if (it->second.main) (void)hipStreamDestroy(it->second.main);
+        g_streams.erase(it);
+    }
+}
+
+
 // bpltv_set_option (include/bpltv.h): aids for tests and measurements; nothing here changes a result.
 struct HandleOptions {
     double adjoint_budget_mb = 0.0;   // > 0: HBM the adjoint's factor workspace may take (forces image groups)
@@ -249,8 +306,10 @@ struct bpltv_handle {
     bool f32_f_valid = false;
     std::map<TabKey, float*> tabs32;
     std::map<GraphKey, std::vector<hipGraphExec_t>> graphs;  // one exec per chain
-    std::vector<hipStream_t> chain_streams;
+    std::vector<hipStream_t> chain_streams;   // the device's (DeviceStreams), not owned
     std::vector<hipEvent_t> chain_events;
+    hipStream_t capture_stream = nullptr;     // the handle's own: stream capture only (nothing ever runs on it); a capture on a shared stream
+                                              // would collide with another handle of the device capturing from its own thread
     // adjoint workspace (lazy)
     bool adj_ready = false;   // common workspace
     bool band_ready = false;  // banded Cholesky workspace (LDS window or HBM band)
@@ -701,11 +760,9 @@ int launch_chains(bpltv_t* h, const std::vector<hipGraphExec_t>& ex, bool thread
     while (h->chain_streams.size() + 1 < ex.size()) {   // chain 0 runs on the handle's own stream
         hipStream_t cs = nullptr;
         hipEvent_t ce = nullptr;
-        HIPCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        if (hipEventCreateWithFlags(&ce, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(cs);
+        HIPCHK(h, device_streams_chain(h->device, h->chain_streams.size(), &cs));   // shared by the handles of the device
+        if (hipEventCreateWithFlags(&ce, hipEventDisableTiming) != hipSuccess)
             return set_err(h, BPLTV_E_HIP, "hipEventCreateWithFlags failed (launch chains)");
-        }
         h->chain_streams.push_back(cs);
         h->chain_events.push_back(ce);
     }
@@ -1586,9 +1643,10 @@ int run_sr_pdhg(bpltv_t* h, const bpltv_params& p) {
                 const int lo = (int)(((long)h->O * c) / nch), hi = (int)(((long)h->O * (c + 1)) / nch);
                 hipGraph_t g = nullptr;
                 hipGraphExec_t ex = nullptr;
-                if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    (void)enqueue_range(h->stream, 0, p.maxiter, 0, lo, hi, (c & 1) && stag);
-                    if (hipStreamEndCapture(h->stream, &g) == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)
+                if (!h->capture_stream && hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess) { h->capture_stream = nullptr; break; }
+                if (hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    (void)enqueue_range(h->capture_stream, 0, p.maxiter, 0, lo, hi, (c & 1) && stag);
+                    if (hipStreamEndCapture(h->capture_stream, &g) == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)
                         exs.push_back(ex);
                     if (g) (void)hipGraphDestroy(g);
                 }
@@ -2364,7 +2422,7 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount;
         h->st.ncu = h->ncu;
     }
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, device_streams_acquire(device, &h->stream));
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
     HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     HIPCHK(h, hipMalloc((void**)&h->d_ubar, h->tot * sizeof(double)));
@@ -2414,8 +2472,8 @@ int bpltv_destroy(bpltv_t* h) {
     h->launcher.reset();   // joins the launcher thread (idle: every call waits for its job)
     drop_graphs(h);
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    for (auto cs : h->chain_streams) (void)hipStreamDestroy(cs);
-    for (auto ce : h->chain_events) (void)hipEventDestroy(ce);
+    for (auto ce : h->chain_events) (void)hipEventDestroy(ce);   // (the chain streams belong to the device: device_streams_release below)
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     for (auto& kv : h->tabs32) (void)hipFree(kv.second);
     for (int s = 0; s < 2; ++s)
@@ -2449,7 +2507,7 @@ int bpltv_destroy(bpltv_t* h) {
     for (int s2 = 0; s2 < 2; ++s2)
         for (int c = 0; c < 7; ++c)
             if (h->d_sr[s2][c]) (void)hipFree(h->d_sr[s2][c]);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream) device_streams_release(h->device);
     delete h;
     return BPLTV_OK;
 }

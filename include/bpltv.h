@@ -20,7 +20,9 @@
  *        1 x 1  scalar alpha;  m x n patch parameter (upsampled piecewise-constant, PatchOp);
  *        M x N  per-pixel map.   grad has the same shape (src/TRBox.jl:37-39,167,237).
  *   - Host pointers are read/written during the call only; the library keeps no host pointer.
- *     One call in flight per handle; calls block until the device work is complete.
+ *     One call in flight per handle; calls block until the device work is complete.  Any number of handles may be
+ *     alive; the handles of one device share its streams (a second handle runs at the speed of the first), so handles
+ *     of the SAME device driven from different host threads at once are serialised on the device, not concurrent.
  *   - bpltv_create drives one GPU.  bpltv_create_multi drives several from ONE host thread (the single
  *     Julia task of src/TRBox.jl:192-273): images block-sharded over the devices, one worker thread and
  *     stream per device inside the library, one RCCL collective over xGMI per evaluation on the
