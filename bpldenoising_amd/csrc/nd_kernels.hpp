@@ -1030,6 +1030,152 @@ __global__ __launch_bounds__(64) void nd_bwd_small_kernel(NdSolveArgs A) {
     }
 }
 
+// The same two substitutions with the front's factor block (f x p doubles, contiguous) STAGED in LDS: the block is fetched
+// by full-width consecutive loads, sixteen per lane in flight and none of them behind a use -- the column loops above touch
+// a front through 2 p partial-line loads of <= f lanes (forward) or walk p columns with one lane each (backward), eight in
+// flight, which is why they move the factor at 2.3 TB/s -- and every dot product then reads LDS.  Same operations in the
+// same order as nd_fwd_small_kernel / nd_bwd_small_kernel: the same bits.  For levels whose fronts have f p <= NDS_STAGE
+// entries (the bottom five levels of a 1024^2 image); dynamic LDS: 8 * (largest f p of the level) bytes.
+constexpr int NDS_STAGE = 2048;
+constexpr int NDS_SU = 16;
+// first the requests of the block's first 64 * NDS_SU entries (issued by the caller ahead of its dependent loads), then
+// their commit to LDS and the rest of the block
+__device__ __forceinline__ void nd_stage_request(const double* __restrict__ src, int n, int lane, double (&t)[NDS_SU]) {
+#pragma unroll
+    for (int u = 0; u < NDS_SU; ++u) t[u] = src[min(64 * u + lane, n - 1)];
+}
+__device__ __forceinline__ void nd_stage_commit(const double* __restrict__ src, double* __restrict__ S, int n, int lane, double (&t)[NDS_SU]) {
+    for (int e0 = 0; e0 < n; e0 += 64 * NDS_SU) {
+        if (e0 > 0) {
+#pragma unroll
+            for (int u = 0; u < NDS_SU; ++u) t[u] = src[min(e0 + 64 * u + lane, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < NDS_SU; ++u) {
+            const int e = e0 + 64 * u + lane;
+            if (e < n) S[e] = t[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void nd_fwd_staged_kernel(NdSolveArgs A) {
+    extern __shared__ double S[];
+    __shared__ double w[128], yv[128];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    const int* px = A.pix + v.piv_off;
+    double* uvi = A.uv + (size_t)img * A.uv_stride;
+    const double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    const double* rhs = A.vec + (size_t)img * A.n;
+    // requests in the order of their dependences: pivot pixel index, the block (needs the descriptor only), then what needs
+    // the index and the children's descriptors -- right-hand side, update vectors and maps
+    const int pxv = lane < p ? px[lane] : 0;
+    double t[NDS_SU];
+    const bool need = !A.lu || b > 0;
+    if (need) nd_stage_request(fc, f * p, lane, t);
+    __builtin_amdgcn_sched_barrier(0);
+    double r0 = 0.0;
+    if (lane < p) r0 = rhs[pxv];
+    int cme[2][2] = {{0, 0}, {0, 0}};
+    double uce[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    int cb[2] = {0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (cn < 0) continue;
+        const NdNodeDev ch = A.nodes[cn];
+        cb[ci] = ch.b;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = lane + 64 * h;
+            if (e < ch.b) { cme[ci][h] = A.cmap[ch.cmap_off + e]; uce[ci][h] = uvi[ch.uv_off + e]; }
+        }
+    }
+    if (need) nd_stage_commit(fc, S, f * p, lane, t);
+    for (int e = lane; e < f; e += 64) w[e] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {                // child 0, then child 1 (a child's entries hit distinct rows)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (lane + 64 * h < cb[ci]) w[cme[ci][h]] += uce[ci][h];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane < p) w[lane] = r0 - w[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* yo = A.y + (size_t)img * A.n;
+    if (lane < p) {                                 // y = W w_p (W lower triangular); LU: y = w_p
+        double acc = 0.0;
+        if (A.lu) acc = w[lane];
+        else
+            for (int c = 0; c <= lane; ++c) acc = __builtin_fma(S[lane + f * c], w[c], acc);
+        yv[lane] = acc;
+        yo[pxv] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < b; i += 64) {            // update vector: children's sums + L21 y
+        double acc = w[p + i];
+        for (int c = 0; c < p; ++c) acc = __builtin_fma(S[(p + i) + f * c], yv[c], acc);
+        uvi[v.uv_off + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void nd_bwd_staged_kernel(NdSolveArgs A) {
+    extern __shared__ double S[];
+    __shared__ double xb[128], z[128];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b;
+    const int* px = A.pix + v.piv_off;
+    double* x = A.vec + (size_t)img * A.n;
+    const double* yo = A.y + (size_t)img * A.n;
+    const double* fc = (A.lu ? A.fac2 : A.fac) + (size_t)img * A.fac_stride + v.fac_off;
+    int pxb[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < b) pxb[h] = px[p + lane + 64 * h];
+    const int pxv = lane < p ? px[lane] : 0;
+    double t[NDS_SU];
+    nd_stage_request(fc, f * p, lane, t);          // the block needs the descriptor only: ahead of the loads that need the indices
+    __builtin_amdgcn_sched_barrier(0);
+    double xr[2] = {0.0, 0.0}, y0 = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < b) xr[h] = x[pxb[h]];
+    if (lane < p) y0 = yo[pxv];
+    nd_stage_commit(fc, S, f * p, lane, t);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < b) xb[lane + 64 * h] = xr[h];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < p) {                                 // z = y_p - L21^T x_b, down column `lane`
+        double acc = y0;
+        const double* col = S + p + f * lane;
+        for (int i = 0; i < b; ++i) acc = __builtin_fma(-col[i], xb[i], acc);
+        z[lane] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < p) {                                 // x_p = W^T z (LU: the whole column of D^-T)
+        const int r0 = A.lu ? 0 : lane;
+        double acc = 0.0;
+        const double* col = S + f * lane;
+        for (int r = r0; r < p; ++r) acc = __builtin_fma(col[r], z[r], acc);
+        x[pxv] = acc;
+        if (A.acc) A.acc[(size_t)img * A.n + pxv] += acc;
+    }
+}
+
 // Large fronts, one workgroup per (front, image).  Dynamic LDS: nd_large_lds(largest front of the batch).
 constexpr int NDL_T = 1024;
 inline size_t nd_large_lds(int fmax) { return sizeof(double) * ((size_t)fmax + 9 * HB2_NB + 64); }

@@ -29,6 +29,7 @@ struct NdSolver {
         int n0 = 0, n1 = 0;
         bool small = true;
         int pmax = 0, bmax = 0, fmax = 0, MPmax = 0, bcmax = 0;   // bcmax: largest child boundary
+        int fpmax = 0;                 // largest factor block (f p entries) of the level
         bool has_child = false;
         long long fac0 = 0, fac_len = 0, ws_len = 0;
         int wave = -1;                 // >= 0: instance of nd_front_wave_kernel (a wave per front) that holds every front of the level
@@ -46,6 +47,7 @@ struct NdSolver {
     std::string err;
     double factor_flop = 0.0;          // per image (multiply-add = 2)
     bool wave_fronts = true;           // Cholesky, fronts of <= 64 rows and <= 32 pivots: nd_front_wave_kernel (false: tools, A/B timing)
+    bool staged_solve = true;          // small levels with f p <= NDS_STAGE: substitutions with the factor block staged in LDS
 
     // the instances of nd_front_wave_kernel<F, P>, smallest first within a pivot class
     struct WaveInst { int F, P; void (*fn)(NdArgs); };
@@ -100,6 +102,7 @@ struct NdSolver {
             for (int q = a.n0; q < a.n1; ++q) {
                 const NdNode& v = T.nodes[q];
                 a.pmax = std::max(a.pmax, v.p); a.bmax = std::max(a.bmax, v.b); a.fmax = std::max(a.fmax, v.p + v.b);
+                a.fpmax = std::max(a.fpmax, (v.p + v.b) * v.p);
                 const int MP = nd_up16(nd_up16(v.p) + v.b);
                 a.MPmax = std::max(a.MPmax, MP);
                 a.fac_len = v.fac_off + (long long)(v.p + v.b) * v.p - a.fac0;
@@ -328,7 +331,8 @@ struct NdSolver {
             for (int q0 = a.n0; q0 < a.n1; q0 += (a.small ? 1 << 20 : 32768)) {
                 S.node0 = q0;
                 const int qn = std::min(a.small ? 1 << 20 : 32768, a.n1 - q0);
-                if (a.small) hipLaunchKernelGGL(nd_fwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
+                if (a.small && staged_solve && a.fpmax <= NDS_STAGE) hipLaunchKernelGGL(nd_fwd_staged_kernel, dim3(qn, nimg), dim3(64), sizeof(double) * a.fpmax, stream, S);
+                else if (a.small) hipLaunchKernelGGL(nd_fwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
                 else {
                     const int split = a.bmax >= 256 ? 1 : 0;   // many boundary rows: L21 y by row blocks, behind the pivot sweep
                     hipLaunchKernelGGL(nd_fwd_large_kernel, dim3(qn, nimg), dim3(NDL_T), nd_large_lds(a.fmax), stream, S, split);
@@ -344,7 +348,8 @@ struct NdSolver {
             for (int q0 = a.n0; q0 < a.n1; q0 += (a.small ? 1 << 20 : 32768)) {
                 S.node0 = q0;
                 const int qn = std::min(a.small ? 1 << 20 : 32768, a.n1 - q0);
-                if (a.small) hipLaunchKernelGGL(nd_bwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
+                if (a.small && staged_solve && a.fpmax <= NDS_STAGE) hipLaunchKernelGGL(nd_bwd_staged_kernel, dim3(qn, nimg), dim3(64), sizeof(double) * a.fpmax, stream, S);
+                else if (a.small) hipLaunchKernelGGL(nd_bwd_small_kernel, dim3(qn, nimg), dim3(64), 0, stream, S);
                 else {
                     const int split = a.bmax >= 256 ? 1 : 0;
                     if (split)
