@@ -47,11 +47,13 @@ class BpltvStats(C.Structure):
         ("collective_ms", C.c_double),
         ("nccl_ranks", C.c_int), ("hb_sync", C.c_int), ("adjoint_chunks", C.c_int),
         ("pdhg_variant", C.c_int),
-        ("ncu", C.c_int), ("launch_chains", C.c_int), ("sweep_shards", C.c_int),
+        ("ncu", C.c_int), ("launch_chains", C.c_int), ("sweep_shards", C.c_int), ("reserved_i", C.c_int),
+        ("launch_host_ms", C.c_double * 2),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "reserved_i", "launch_host_ms")}
+        d["launch_host_ms"] = [self.launch_host_ms[0], self.launch_host_ms[1]]
         d["adjoint_method"] = {1: "band", 2: "bcr", 3: "band-hbm", 4: "band-lu", 5: "nd", 6: "nd-lu"}.get(self.adjoint_method, "")
         d["hb_sync"] = {0: "", 1: "event", 2: "value"}.get(self.hb_sync, "")
         d["collective"] = {0: "none", 1: "ncclAllReduce", 2: "ncclAllGather+ordered sum", 3: "host sum"}.get(self.collective, "")

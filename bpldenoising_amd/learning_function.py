@@ -114,6 +114,7 @@ class TVSolver:
         chains = kw.pop("chains", None)
         serialize = kw.pop("serialize_chains", None)
         xcd = kw.pop("xcd", None)
+        one_thread = kw.pop("one_thread", None)
         adjm = kw.pop("adjoint_method", None)
         for k, v in kw.items():
             if k in _IGNORED:
@@ -131,6 +132,8 @@ class TVSolver:
             p.reserved[2] = int(bool(serialize))  # replay launch chains one after the other (timing aid)
         if xcd is not None:
             p.reserved[2] |= 2 * int(xcd)        # 1: XCD-aware tile order, 2: natural order (0 = by image size)
+        if one_thread:
+            p.reserved[2] |= 8                   # both launch chains from the calling thread (timing aid)
         if adjm is not None:
             p.reserved[4] = {"auto": 0, "band": 1, "bcr": 2, "nd": 3}.get(adjm, adjm)  # adjoint factorisation
         return p

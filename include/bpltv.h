@@ -152,6 +152,9 @@ typedef struct bpltv_stats {
     int launch_chains;         /* independent launch chains (image groups replayed concurrently) of the last solve */
     int sweep_shards;          /* last bpltv_sweep of a multi handle: devices the K parameter blocks were split over
                                   (replica mode), 0 = the images were split / single device                        */
+    int reserved_i;
+    double launch_host_ms[2];  /* host time the last solve's hipGraphLaunch calls took: chain 0 (calling thread) and
+                                  chain 1 (launcher thread); 0 when the solve had one chain or ran without graphs    */
 } bpltv_stats_t;
 
 #define BPLTV_RESIDUAL_GATE 1e-6

@@ -1,0 +1,30 @@
+"""Per-step PDHG event times of the headline workload (round 4): how much of the mean is jitter?
+usage: python tools/step_jitter.py [steps]  (GPU box)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+import bpldenoising_amd as B
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+kw = {"maxiter": 5000}
+for a in sys.argv[2:]:
+    k, v = a.split("=")
+    kw[k] = int(v)
+ub, f, _ = bench.load_batch("faces_train_128_10", 10, 128, 128, 20211004)
+s = B.TVSolver(128, 128, 10)
+s.set_data(ub, f)
+for _ in range(3):
+    s.denoise(0.1, fetch=False, **kw)
+ev, wall, l0, l1 = [], [], [], []
+for _ in range(steps):
+    t0 = time.perf_counter()
+    s.denoise(0.1, fetch=False, **kw)
+    wall.append(1e3 * (time.perf_counter() - t0))
+    st = s.stats(); ev.append(st["pdhg_ms"]); l0.append(st["launch_host_ms"][0]); l1.append(st["launch_host_ms"][1])
+ev, wall = np.array(ev), np.array(wall)
+print(kw, "event ms: min %.3f median %.3f mean %.3f max %.3f" % (ev.min(), np.median(ev), ev.mean(), ev.max()))
+print("wall  ms: min %.3f median %.3f mean %.3f max %.3f" % (wall.min(), np.median(wall), wall.mean(), wall.max()))
+l0, l1 = np.array(l0), np.array(l1)
+slow = ev > 1.1 * ev.min()
+print("host ms of hipGraphLaunch, chain 0 / chain 1: fast steps %.3f / %.3f, slow steps %.3f / %.3f" % (l0[~slow].mean(), l1[~slow].mean(), l0[slow].mean() if slow.any() else 0, l1[slow].mean() if slow.any() else 0))
+print("slow steps (> 1.1 x min): %d of %d; launches %d" % ((ev > 1.1 * ev.min()).sum(), steps, s.stats()["launches"]))
