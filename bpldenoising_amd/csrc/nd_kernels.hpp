@@ -1178,7 +1178,8 @@ __global__ __launch_bounds__(64) void nd_bwd_staged_kernel(NdSolveArgs A) {
 
 // Large fronts, one workgroup per (front, image).  Dynamic LDS: nd_large_lds(largest front of the batch).
 constexpr int NDL_T = 1024;
-inline size_t nd_large_lds(int fmax) { return sizeof(double) * ((size_t)fmax + 9 * HB2_NB + 64); }
+constexpr int NDL_RB = 4;     // row blocks (forward) / columns per wave (backward) whose loads are in flight together
+inline size_t nd_large_lds(int fmax) { return sizeof(double) * ((size_t)fmax + (1 + 8 * NDL_RB) * HB2_NB + 64); }
 
 // forward: wf = [rhs_p - s_p ; -s_b]; per pivot panel: y_k = W_kk wf_k, then wf[r] -= L(r, panel k) y_k for every row
 // below; update vector = -wf_b.  grid (nodes, nimg), block NDL_T.
@@ -1233,21 +1234,31 @@ __global__ __launch_bounds__(NDL_T) void nd_fwd_large_kernel(NdSolveArgs A, int 
             }
             __syncthreads();
         }
-        // rows below the diagonal block: wf[r] -= sum_c L(r, c0 + c) y[c]; 128 rows x 8 column groups per pass
+        // rows below the diagonal block: wf[r] -= sum_c L(r, c0 + c) y[c]; 128 rows x 8 column groups per row block, NDL_RB
+        // row blocks per pass: their loads (16 per thread and block) are in flight together -- one workgroup streams a
+        // front of up to 12 MB, and what it moves per second is what it has in flight.  Same sums in the same order.
         const int rend = split ? p : f;
-        for (int R0 = c0 + nb; R0 < rend; R0 += HB2_NB) {
-            const int r = R0 + r128;
-            double acc = 0.0;
-            if (r < rend) {
-                const double* Lr = fc + r + (size_t)f * c0;
-                for (int c = g8; c < nb; c += 8) acc = __builtin_fma(Lr[(size_t)f * c], wf[c0 + c], acc);
+        for (int R0 = c0 + nb; R0 < rend; R0 += NDL_RB * HB2_NB) {
+            double acc[NDL_RB];
+#pragma unroll
+            for (int q = 0; q < NDL_RB; ++q) acc[q] = 0.0;
+            for (int c = g8; c < nb; c += 8) {
+                const double yc = wf[c0 + c];
+#pragma unroll
+                for (int q = 0; q < NDL_RB; ++q) {
+                    const int r = R0 + q * HB2_NB + r128;
+                    const double l = fc[min(r, rend - 1) + (size_t)f * (c0 + c)];
+                    acc[q] = __builtin_fma(r < rend ? l : 0.0, yc, acc[q]);
+                }
             }
-            part[g8 * HB2_NB + r128] = acc;
+#pragma unroll
+            for (int q = 0; q < NDL_RB; ++q) part[(q * 8 + g8) * HB2_NB + r128] = acc[q];
             __syncthreads();
-            if (tid < HB2_NB && R0 + tid < rend) {
+            if (tid < NDL_RB * HB2_NB && R0 + tid < rend) {
+                const int q = tid >> 7, t = tid & 127;
                 double s = 0.0;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) s += part[g * HB2_NB + tid];
+                for (int g = 0; g < 8; ++g) s += part[(q * 8 + g) * HB2_NB + t];
                 wf[R0 + tid] -= s;
             }
             __syncthreads();
@@ -1337,13 +1348,24 @@ __global__ __launch_bounds__(NDL_T) void nd_bwd_large_kernel(NdSolveArgs A, int 
     const int rend = split ? p : f;
     for (int k = npan - 1; k >= 0; --k) {
         const int c0 = HB2_NB * k, nb = min(HB2_NB, p - c0), rlo = c0 + nb;
-        for (int c = wave; c < nb; c += NDL_T / 64) {
-            const double* col = fc + (size_t)f * (c0 + c);
-            double acc = 0.0;
-            for (int r = rlo + lane; r < rend; r += 64) acc = __builtin_fma(col[r], vf[r], acc);
+        for (int cb = wave * NDL_RB; cb < nb; cb += (NDL_T / 64) * NDL_RB) {   // NDL_RB columns per wave at a time: their loads in flight together
+            double acc[NDL_RB];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-            if (lane == 0) tt[c] = yo[px[c0 + c]] - acc;
+            for (int q = 0; q < NDL_RB; ++q) acc[q] = 0.0;
+            for (int r = rlo + lane; r < rend; r += 64) {
+                const double vr = vf[r];
+#pragma unroll
+                for (int q = 0; q < NDL_RB; ++q) {
+                    const double l = fc[r + (size_t)f * (c0 + min(cb + q, nb - 1))];
+                    acc[q] = __builtin_fma(l, vr, acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NDL_RB; ++q) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+                if (lane == 0 && cb + q < nb) tt[cb + q] = yo[px[c0 + cb + q]] - acc[q];
+            }
         }
         __syncthreads();
         // x_k = W_kk^T t: x[c] = sum_{r >= c} W(r, c) t[r]; thread (column c = tid & 127, row group g8)
