@@ -308,6 +308,7 @@ struct bpltv_handle {
     std::map<GraphKey, std::vector<hipGraphExec_t>> graphs;  // one exec per chain
     std::vector<hipStream_t> chain_streams;   // the device's (DeviceStreams), not owned
     std::vector<hipEvent_t> chain_events;
+    unsigned* d_phase = nullptr;              // the word chain 0's launches rewrite (PDHG_PHASE_STAMP, pdhg_phase_gate_kernel)
     hipStream_t capture_stream = nullptr;     // the handle's own: stream capture only (nothing ever runs on it); a capture on a shared stream
                                               // would collide with another handle of the device capturing from its own thread
     // adjoint workspace (lazy)
@@ -632,7 +633,25 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         const int h0 = pl.T / 2;
         const bool stagger = (c & 1) && chain_out_of_phase(niter, pl.T, from_state);
         int step = stagger ? h0 : pl.T;
+        // two chains: chain 0 stamps its launches, chain 1 falls in at the middle of chain 0's period after its 8th launch,
+        // (pdhg_phase_gate_kernel; not in a serial replay's graphs, reserved[2] & 1: a timing aid)
+        // (LDS-tile kernels only: launches of ~10 us; the row kernels' launches of ~100 us showed one kind of step only)
+        const bool phased = pl.chains == 2 && h->d_phase != nullptr && !(p.reserved[2] & 1) && niter / pl.T >= 64 && V.RI <= 48;
+        int nlaunch = 0;
         for (int it = 0; it < niter; it += step, step = pl.T) {
+            if (phased && c == 1 && (nlaunch == 8 || nlaunch == 40 || nlaunch == 160)) {   // 40, 160: a check, in case the sequence fell back
+                unsigned* ph = h->d_phase;
+                int check = nlaunch == 8 ? 0 : 1;
+                void* gargs[] = {(void*)&ph, (void*)&check};
+                hipKernelNodeParams gp;
+                std::memset(&gp, 0, sizeof(gp));
+                gp.func = reinterpret_cast<void*>(&pdhg_phase_gate_kernel);
+                gp.gridDim = dim3(1); gp.blockDim = dim3(64); gp.sharedMemBytes = 0; gp.kernelParams = gargs; gp.extra = nullptr;
+                hipGraphNode_t gate = nullptr;
+                if (hipGraphAddKernelNode(&gate, g, prev ? &prev : nullptr, prev ? 1 : 0, &gp) == hipSuccess) prev = gate;
+                else (void)hipGetLastError();
+            }
+            ++nlaunch;
             PdhgArgs a;
             a.f = pdhg_f(h); a.alpha = pdhg_alpha(h); a.tab = d_tab; a.rho = p.rho;
             a.am = h->last_am; a.an = h->last_an;
@@ -640,6 +659,7 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
             a.Odata = h->O; a.astride = h->cur_astride;
             a.nTi = pl.nTi; a.nTj = pl.nTj; a.halo = pl.T; a.seg = V.RJ;
             a.img0 = lo;
+            a.phase = (phased && c == 0) ? h->d_phase : nullptr;
 #ifdef BPLTV_EXPERIMENTS
             a.dbg = p.reserved[3];
 #endif
@@ -883,7 +903,7 @@ int run_pdhg(bpltv_t* h, const bpltv_params& p) {
     if (!chunked) {
         bool done = main_iters == 0;
         if (p.use_graph && !done) {
-            GraphKey key{main_iters, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3] | ((p.reserved[2] & 2) << 16), h->cur_nimg, (const void*)pdhg_state(h, 0, 0), (const void*)d_tab, from_state ? 1 : 0};
+            GraphKey key{main_iters, pl.T, pl.variant, h->last_am, h->last_an, pl.chains, p.rho, p.tau0, p.sigma0, p.accel ? 1 : 0, p.reserved[3] | ((p.reserved[2] & 3) << 16), h->cur_nimg, (const void*)pdhg_state(h, 0, 0), (const void*)d_tab, from_state ? 1 : 0};
             auto it = h->graphs.find(key);
             const int nl = (main_iters + pl.T - 1) / pl.T;
             if (it == h->graphs.end() && h->graphs.size() >= 16) {  // bounded cache
@@ -2428,6 +2448,8 @@ int bpltv_create(bpltv_t** out, int M, int N, int O, int device, int dtype) {
     HIPCHK(h, device_streams_acquire(device, &h->stream));
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
     HIPCHK(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    HIPCHK(h, hipMalloc((void**)&h->d_phase, 64));
+    HIPCHK(h, hipMemset(h->d_phase, 0, 64));
     HIPCHK(h, hipMalloc((void**)&h->d_ubar, h->tot * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->d_f, h->tot * sizeof(double)));
     for (int s = 0; s < 2; ++s)
@@ -2477,6 +2499,7 @@ int bpltv_destroy(bpltv_t* h) {
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     for (auto ce : h->chain_events) (void)hipEventDestroy(ce);   // (the chain streams belong to the device: device_streams_release below)
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    if (h->d_phase) (void)hipFree(h->d_phase);
     for (auto& kv : h->tabs) (void)hipFree(kv.second);
     for (auto& kv : h->tabs32) (void)hipFree(kv.second);
     for (int s = 0; s < 2; ++s)
@@ -2942,3 +2965,10 @@ const char* bpltv_last_error(bpltv_t* h) {
 
 }  // extern "C"
 #pragma GCC visibility pop
+
+#ifdef BPLTV_EXPERIMENTS
+// tools/chain_phase.py: the launch-start stamps of the last solve run with params.reserved[3] & 1024 (2 x 4096 ticks of 10 ns)
+extern "C" __attribute__((visibility("default"))) int bpltv_debug_tlog(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bpltv::pdhg_tlog), sizeof(long long) * 2 * 4096) == hipSuccess ? 0 : 2;
+}
+#endif

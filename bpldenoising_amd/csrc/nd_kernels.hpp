@@ -151,6 +151,7 @@ __device__ __forceinline__ bool nd_partial_potrf(double* __restrict__ S, int MP,
 }
 
 constexpr int NDS_T = 256;
+constexpr int NDS_CU = 4;     // children's update-matrix columns in flight per wave (nd_front_small_kernel; 8 measured: no gain)
 inline size_t nd_small_lds(int MP) { return sizeof(double) * ((size_t)(MP + 1) * MP + MP); }
 
 // One workgroup per (front, image).  grid (nodes of the batch, nimg), block NDS_T, dynamic LDS nd_small_lds(MPmax).
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
         const double* Uc = A.ws_child + (size_t)img * A.ws_child_stride + ch[ci].u_off;
         const int n = bc[ci];
         const int* cm = cmL[ci];
-        for (int j0 = wave; j0 < n; j0 += 4 * NW) {      // four columns per wave and pass: their loads are in flight together
-            double x[4][2];
+        for (int j0 = wave; j0 < n; j0 += NDS_CU * NW) {   // NDS_CU columns per wave and pass: their loads are in flight together
+            double x[NDS_CU][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NDS_CU; ++u) {
                 const int j = j0 + u * NW;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NDS_CU; ++u) {
                 const int j = j0 + u * NW;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {

@@ -59,6 +59,8 @@ struct PdhgArgs {
     int xcd;    // 1 (1-D grid only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2; remap the
                 // linear workgroup index so that every XCD works on a contiguous run of tiles (neighbouring tiles re-read
                 // each other's halos: from the same L2 instead of from the memory side)
+    unsigned* phase = nullptr;   // chain 0 of a two-chain solve: a word the first workgroup of every launch rewrites (first iteration of
+                // the launch + 1, PDHG_PHASE_STAMP) -- pdhg_phase_gate_kernel in the other chain waits for it to change
 #ifdef BPLTV_EXPERIMENTS
     int dbg;    // timing experiments of tools/ builds only (results are wrong): 1 skip state loads, 2 skip
                 // stores, 4 no iterations, 16 nt stores, 32 plain stores, 64 nt loads, 128 no barriers (rows kernel).  The product
@@ -68,13 +70,28 @@ struct PdhgArgs {
 
 #ifdef BPLTV_EXPERIMENTS
 #define BPLTV_DBG(A) ((A).dbg)
+// dbg & 1024 (tools/chain_phase.py): the first workgroup of every launch stamps the 100 MHz clock at its start into
+// pdhg_tlog[chain][launch] -- how the launches of the two chains of a solve lie relative to each other
+__device__ long long pdhg_tlog[2][4096];
+#define PDHG_TLOG(A)                                                                                                   \
+    if (((A).dbg & 1024) && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)                  \
+        pdhg_tlog[(A).img0 != 0][min(4095, ((A).it0 + (A).halo - 1) / max((A).halo, 1))] = (long long)wall_clock64();
 #else
 #define BPLTV_DBG(A) 0
+#define PDHG_TLOG(A)
 #endif
 
 // Tile (ta, tb) and image of the launch (imgl) of this workgroup; dataset image and parameter block of a solve image
 // (parameter sweeps run K * Odata problems: image `img` uses f[img % Odata] and parameter block img / Odata).
+// One plain store by one thread.  Anything here that waits for a value costs the whole launch: a launch lasts as long as its
+// slowest workgroup, and an atomicAdd (or a clock read plus a load of the previous stamp) in the first workgroup's prologue
+// made EVERY launch 25-30 % longer (5.22 -> 6.7 ms per 5000 iterations).
+#define PDHG_PHASE_STAMP(A)                                                                              \
+    if ((A).phase != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+        *(A).phase = (unsigned)(A).it0 + 1u;
 #define PDHG_DECODE_BLOCK(A, imgl, ta, tb)                                   \
+    PDHG_PHASE_STAMP(A)                                                      \
+    PDHG_TLOG(A)                                                             \
     int imgl, ta, tb;                                                        \
     if ((A).grid3d) {                                                        \
         ta = (int)blockIdx.x; tb = (int)blockIdx.y; imgl = (int)blockIdx.z;  \
@@ -1273,14 +1290,50 @@ __global__ __launch_bounds__(64 * WPB, 2) void pdhg_wave_kernel(PdhgArgs A) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Non-default starts of the recurrence (bpltv_params.init / order: the choices the reference does not pin,
-// DESIGN.md section 2.3; checker: bplo_pdhg_opts of the oracle).  The hot kernel above is not touched: a
-// dual-first run is   y <- dual step from xbar0 = x0 (this kernel)  ->  pdhg_tile_kernel for maxiter - 1
-// iterations on a step table whose row k carries sigma_{k+1}  ->  the last primal step (pdhg_xstep_kernel).
-// ------------------------------------------------------------------------------------------
-// x0 = f (init 0) or 0 (init 1); y0 = 0, or -- dual_first -- the dual step of iteration 0 from xbar0 = x0:
-// the arithmetic of pdhg_y_pass (oracle) with y = 0.  One thread per pixel of every solve image.
+// Two launch chains of equal launches have two stable ways of sharing the chip (tools/chain_phase.py stamps every launch):
+// OUT of phase -- chain 1's launches start at 0.45-0.58 of chain 0's period, one chain's launch gap falls into the other's
+// arithmetic, 5.22 ms per 5000 iterations of the reference batch -- and IN phase -- both chains launch together and
+// compute together, phase 0.00 +- 0.05 for the whole sequence, 6.55 ms: the rate of a single chain.  Which one a solve
+// falls into is settled in its first few launches and not by anything the host controls (8-36 % of the solves were slow
+// ones, tools/step_jitter.py).  This one-wave kernel sits in chain 1's graph a few launches in.  It watches the word chain
+// 0's launches rewrite, times two consecutive launch starts of chain 0 (its own clock reads cost nothing: it is the only
+// wave of its launch) and holds chain 1's queue until the MIDDLE of chain 0's period; both states being stable the sequence
+// stays out of phase from there.  (Letting chain 1 go right at a launch start of chain 0 did the opposite: its next launch
+// is queued already and starts within a fraction of a period -- 30-40 % slow solves.)  About two periods per solve,
+// <= 0.4 % of it; never longer than 200 us (chain 0 finished or not running: nothing changes the word).
+// check != 0 (later in the sequence): the period is the one the first gate measured (phase[1]); chain 1 is held only if
+// chain 0's next launch start comes within 15 % of a period of this kernel's own start or later than 85 % -- in phase;
+// otherwise the kernel ends after half a period on average.
+__global__ __launch_bounds__(64) void pdhg_phase_gate_kernel(unsigned* __restrict__ phase, int check) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = (long long)wall_clock64();                       // 100 MHz
+    long long ta[2] = {0, 0};
+    unsigned c = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nobs = check ? 1 : 2;
+    for (int k = 0; k < nobs; ++k) {
+        unsigned n = c;
+        while ((n = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == c) {
+            if ((long long)wall_clock64() - t0 > 20000) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ta[k] = (long long)wall_clock64();
+        c = n;
+    }
+    long long per, last;
+    if (check) {
+        per = (long long)phase[1];
+        last = ta[0];
+        const long long d = last - t0;
+        if (per < 100 || per > 20000 || (20 * d > 3 * per && 20 * d < 17 * per)) return;   // no period on record, or out of phase
+    } else {
+        per = ta[1] - ta[0];
+        last = ta[1];
+        phase[1] = (unsigned)per;
+    }
+    const long long until = last + per / 2;
+    while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(1);
+}
+
 __global__ __launch_bounds__(256) void pdhg_init_kernel(const double* __restrict__ f, const double* __restrict__ alpha,
                                                         int am, int an, int M, int N, int Odata, int astride, size_t total,
                                                         int init, int dual_first, double sigma, double rho,

@@ -7,22 +7,26 @@ import bench
 import bpldenoising_amd as B
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 kw = {"maxiter": 5000}
+size, images = 128, 10
 for a in sys.argv[2:]:
     k, v = a.split("=")
-    kw[k] = int(v)
-ub, f, _ = bench.load_batch("faces_train_128_10", 10, 128, 128, 20211004)
-s = B.TVSolver(128, 128, 10)
+    if k == "size": size = int(v)
+    elif k == "images": images = int(v)
+    else: kw[k] = int(v)
+ub, f, _ = bench.load_batch("faces_train_128_10" if size == 128 else "synthetic", images, size, size, 20211004)
+s = B.TVSolver(size, size, images)
+alpha = 0.1 if size == 128 else 0.05 + 0.1 * np.random.default_rng(3).random((size, size))
 s.set_data(ub, f)
 for _ in range(3):
-    s.denoise(0.1, fetch=False, **kw)
+    s.denoise(alpha, fetch=False, **kw)
 ev, wall, l0, l1 = [], [], [], []
 for _ in range(steps):
     t0 = time.perf_counter()
-    s.denoise(0.1, fetch=False, **kw)
+    s.denoise(alpha, fetch=False, **kw)
     wall.append(1e3 * (time.perf_counter() - t0))
     st = s.stats(); ev.append(st["pdhg_ms"]); l0.append(st["launch_host_ms"][0]); l1.append(st["launch_host_ms"][1])
 ev, wall = np.array(ev), np.array(wall)
-print(kw, "event ms: min %.3f median %.3f mean %.3f max %.3f" % (ev.min(), np.median(ev), ev.mean(), ev.max()))
+print(kw, size, images, "event ms: min %.3f median %.3f mean %.3f max %.3f" % (ev.min(), np.median(ev), ev.mean(), ev.max()))
 print("wall  ms: min %.3f median %.3f mean %.3f max %.3f" % (wall.min(), np.median(wall), wall.mean(), wall.max()))
 l0, l1 = np.array(l0), np.array(l1)
 slow = ev > 1.1 * ev.min()
