@@ -7,22 +7,24 @@ import bench
 import bpldenoising_amd as B
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 kw = {"maxiter": 5000}
-size, images = 128, 10
+size, images, sumregs = 128, 10, 0
 for a in sys.argv[2:]:
     k, v = a.split("=")
     if k == "size": size = int(v)
+    elif k == "sumregs": sumregs = int(v)
     elif k == "images": images = int(v)
     else: kw[k] = int(v)
 ub, f, _ = bench.load_batch("faces_train_128_10" if size == 128 else "synthetic", images, size, size, 20211004)
 s = B.TVSolver(size, size, images)
 alpha = 0.1 if size == 128 else 0.05 + 0.1 * np.random.default_rng(3).random((size, size))
 s.set_data(ub, f)
+step = (lambda: s.sumregs_denoise(np.array([0.05, 0.03, 0.02]), fetch=False, **kw)) if sumregs else (lambda: s.denoise(alpha, fetch=False, **kw))
 for _ in range(3):
-    s.denoise(alpha, fetch=False, **kw)
+    step()
 ev, wall, l0, l1 = [], [], [], []
 for _ in range(steps):
     t0 = time.perf_counter()
-    s.denoise(alpha, fetch=False, **kw)
+    step()
     wall.append(1e3 * (time.perf_counter() - t0))
     st = s.stats(); ev.append(st["pdhg_ms"]); l0.append(st["launch_host_ms"][0]); l1.append(st["launch_host_ms"][1])
 ev, wall = np.array(ev), np.array(wall)
