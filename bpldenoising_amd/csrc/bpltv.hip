@@ -635,8 +635,10 @@ int build_graphs(bpltv_t* h, const bpltv_params& p, const Plan& pl, const double
         int step = stagger ? h0 : pl.T;
         // two chains: chain 0 stamps its launches, chain 1 falls in at the middle of chain 0's period after its 8th launch,
         // (pdhg_phase_gate_kernel; not in a serial replay's graphs, reserved[2] & 1: a timing aid)
-        // (LDS-tile kernels only: launches of ~10 us; the row kernels' launches of ~100 us showed one kind of step only)
-        const bool phased = pl.chains == 2 && h->d_phase != nullptr && !(p.reserved[2] & 1) && niter / pl.T >= 64 && V.RI <= 48;
+        // (LDS-tile kernels only: launches of ~10 us; the row kernels' launches of ~100 us showed one kind of step only;
+        // and launches of at most two workgroups per CU: longer ones -- sweeps of many problems -- are not launch-bound)
+        const bool phased = pl.chains == 2 && h->d_phase != nullptr && !(p.reserved[2] & 1) && niter / pl.T >= 64 && V.RI <= 48 &&
+                            (long)tilesPerImg * h->cur_nimg <= 4L * (h->ncu > 0 ? h->ncu : 256);
         int nlaunch = 0;
         for (int it = 0; it < niter; it += step, step = pl.T) {
             if (phased && c == 1 && (nlaunch == 8 || nlaunch == 40 || nlaunch == 160)) {   // 40, 160: a check, in case the sequence fell back

@@ -457,7 +457,10 @@ __global__ __launch_bounds__(64) void nd_front_wave_kernel(NdArgs A) {
 // 1; zero where neither reaches), through the parent -> child maps `inv`.  No zero pass, no read-modify-write, no
 // atomics; nd_orig_kernel adds the few matrix entries afterwards.  A wave per front column, lanes down the rows: the
 // maps are monotone, so a wave reads runs of consecutive child entries.  grid (blocks, nodes, nimg), block 256.
-constexpr int NDG_U = 8;
+// Round 4: a wave takes NDG_C consecutive columns at a time; the row maps of a chunk of rows are loaded once for all of
+// them, and every load is unconditional (clamped index, select afterwards) -- with a load under an `if` the compiler parks
+// each one behind its own exec mask and waits for it there, so the "chunks in flight" of the earlier form were one.
+constexpr int NDG_U = 4, NDG_C = 4;
 __global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
     const int node = A.node0 + blockIdx.y, img = blockIdx.z;
     const NdNodeDev v = A.nodes[node];
@@ -466,33 +469,49 @@ __global__ __launch_bounds__(256) void nd_gather_kernel(NdArgs A) {
     double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
     const bool has = v.inv_off >= 0;
     const int* inv0 = A.inv + (has ? v.inv_off : 0);
-    const int* inv1 = inv0 + f;
-    const double *U0 = nullptr, *U1 = nullptr;
+    const int* inv1 = inv0 + (has ? f : 0);
+    const double *U0 = A.ws_child, *U1 = A.ws_child;     // a valid address also without the child: nothing read from it is used
     int b0 = 0, b1 = 0;
-    if (has && v.child0 >= 0) { const NdNodeDev ch = A.nodes[v.child0]; U0 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b0 = ch.b; }
-    if (has && v.child1 >= 0) { const NdNodeDev ch = A.nodes[v.child1]; U1 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b1 = ch.b; }
+    bool h0 = false, h1 = false;
+    if (has && v.child0 >= 0) { const NdNodeDev ch = A.nodes[v.child0]; U0 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b0 = ch.b; h0 = true; }
+    if (has && v.child1 >= 0) { const NdNodeDev ch = A.nodes[v.child1]; U1 = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off; b1 = ch.b; h1 = true; }
     const int lane = threadIdx.x & 63;
-    for (int C = blockIdx.x * 4 + (threadIdx.x >> 6); C < f; C += gridDim.x * 4) {
-        const int c0 = U0 ? inv0[C] : -1, c1 = U1 ? inv1[C] : -1;
-        double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
-        const double* s0 = c0 >= 0 ? U0 + (size_t)b0 * c0 : nullptr;
-        const double* s1 = c1 >= 0 ? U1 + (size_t)b1 * c1 : nullptr;
-        for (int R0 = C; R0 < f; R0 += 64 * NDG_U) {   // NDG_U row chunks in flight per lane (index, then value: two dependent round trips each)
-            double x[NDG_U];
+    for (int Cg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NDG_C; Cg < f; Cg += gridDim.x * 4 * NDG_C) {
+        int c0[NDG_C], c1[NDG_C];
+#pragma unroll
+        for (int q = 0; q < NDG_C; ++q) {
+            const int C = min(Cg + q, f - 1);
+            c0[q] = h0 ? inv0[C] : -1;                  // wave-uniform
+            c1[q] = h1 ? inv1[C] : -1;
+        }
+        for (int R0 = Cg; R0 < f; R0 += 64 * NDG_U) {
+            int a0[NDG_U], a1[NDG_U];
 #pragma unroll
             for (int u = 0; u < NDG_U; ++u) {
-                const int R = R0 + lane + 64 * u;
-                double acc = 0.0;
-                if (R < f) {
-                    if (s0) { const int a = inv0[R]; if (a >= 0) acc = s0[a]; }
-                    if (s1) { const int a = inv1[R]; if (a >= 0) acc += s1[a]; }
-                }
-                x[u] = acc;
+                const int R = min(R0 + lane + 64 * u, f - 1);
+                a0[u] = inv0[has ? R : 0];
+                a1[u] = inv1[has ? R : 0];
             }
+            double x0[NDG_C][NDG_U], x1[NDG_C][NDG_U];
 #pragma unroll
-            for (int u = 0; u < NDG_U; ++u) {
-                const int R = R0 + lane + 64 * u;
-                if (R < f) dst[R] = x[u];
+            for (int q = 0; q < NDG_C; ++q)
+#pragma unroll
+                for (int u = 0; u < NDG_U; ++u) {
+                    const bool k0 = h0 && c0[q] >= 0 && a0[u] >= 0, k1 = h1 && c1[q] >= 0 && a1[u] >= 0;
+                    x0[q][u] = U0[k0 ? (size_t)a0[u] + (size_t)b0 * c0[q] : 0];
+                    x1[q][u] = U1[k1 ? (size_t)a1[u] + (size_t)b1 * c1[q] : 0];
+                }
+#pragma unroll
+            for (int q = 0; q < NDG_C; ++q) {
+                const int C = Cg + q;
+                double* dst = (C < p) ? fc + (size_t)f * C : U + (size_t)b * (C - p) - p;   // column C of the front, indexed by front row
+#pragma unroll
+                for (int u = 0; u < NDG_U; ++u) {
+                    const int R = R0 + lane + 64 * u;
+                    const bool k0 = h0 && c0[q] >= 0 && a0[u] >= 0, k1 = h1 && c1[q] >= 0 && a1[u] >= 0;
+                    const double acc = (k0 ? x0[q][u] : 0.0) + (k1 ? x1[q][u] : 0.0);
+                    if (C < f && R < f && R >= C) dst[R] = acc;
+                }
             }
         }
     }

@@ -238,7 +238,7 @@ struct NdSolver {
             for (int q0 = a.n0; q0 < a.n1; q0 += 32768) {     // grid.y <= 65535
                 const int qn = std::min(32768, a.n1 - q0);
                 A.node0 = q0;
-                hipLaunchKernelGGL(nd_gather_kernel, dim3(std::max(1, std::min((a.fmax + 3) / 4, 128)), qn, nimg), dim3(256), 0, stream, A);
+                hipLaunchKernelGGL(nd_gather_kernel, dim3(std::max(1, std::min((a.fmax + 4 * NDG_C - 1) / (4 * NDG_C), 128)), qn, nimg), dim3(256), 0, stream, A);
                 hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, A);
                 const int npan = (a.pmax + HB2_NB - 1) / HB2_NB;
                 for (int k = 0; k < npan; ++k) {
@@ -291,7 +291,7 @@ struct NdSolver {
                 const int qn = std::min(32768, a.n1 - q0);
                 NdArgs AL = args(0), AU = args(1);
                 AL.node0 = AU.node0 = q0;
-                const dim3 gg(std::max(1, std::min((a.fmax + 3) / 4, 128)), qn, nimg);
+                const dim3 gg(std::max(1, std::min((a.fmax + 4 * NDG_C - 1) / (4 * NDG_C), 128)), qn, nimg);
                 hipLaunchKernelGGL(nd_gather_kernel, gg, dim3(256), 0, stream, AL);
                 hipLaunchKernelGGL(nd_gather_kernel, gg, dim3(256), 0, stream, AU);
                 hipLaunchKernelGGL(nd_orig_kernel, dim3(qn, nimg), dim3(256), 0, stream, AL);
