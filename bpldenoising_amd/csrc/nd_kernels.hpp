@@ -248,6 +248,159 @@ __global__ __launch_bounds__(NT, BIG ? 2 : 4 * NT / 256) void nd_front_small_ker
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// small regime, SKINNY fronts: p <= 16 pivots, up to 128 rows -- the front is never assembled
+// ------------------------------------------------------------------------------------------------------------------
+// The two levels below the large regime (1024^2: 49 152 fronts of 7 .. 16 pivots and 45 .. 109 rows per eight images).
+// nd_front_small_kernel assembles such a front as a 112 x 113 image in LDS -- 101 KB: ONE workgroup per CU -- although almost
+// all of it is the update matrix, which only passes through: U = (children's entries that land in F22) - L21 L21^T.  Here
+// only the pivot block column lives in LDS (MP x 16, 16.5 KB: eight workgroups per CU): matrix entries and the children's
+// entries in gather form through the parent -> child maps (`inv`, as nd_gather_kernel; the host builds them for these
+// levels too), factored by wave 0 (bcr_panel_factor, the pivot chain of nd_partial_potrf) while the other waves already
+// request the children's entries of their first update-matrix tiles; then every 16 x 16 tile of U is produced once:
+// the gathered sum (child 0 + child 1) as the MFMA accumulator, minus L21_i L21_j^T (one block column: four
+// v_mfma_f64_16x16x4), straight to HBM.  Same operations in the same order as nd_front_small_kernel: the same bits.
+// grid (fronts of the level, nimg), block 256; dynamic LDS nd_skinny_lds(MPmax).
+inline size_t nd_skinny_lds(int MP) { return sizeof(double) * ((size_t)(MP + 1) * 16 + 16) + sizeof(int) * 2 * 128; }
+
+__global__ __launch_bounds__(256, 3) void nd_front_skinny_kernel(NdArgs A) {
+    extern __shared__ double S[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, sh = 16 - p;              // boundary row i of the front sits at panel row 16 + i
+    const int MP = 16 + nd_up16(b), ld = MP + 1, P = MP >> 4;
+    double* dinv = S + (size_t)ld * 16;
+    int* iv = reinterpret_cast<int*>(dinv + 16);                     // iv[ci * 128 + front row]: index in child ci's boundary, or -1
+    const bool has = v.inv_off >= 0;
+    const double* Uc[2] = {A.ws_child, A.ws_child};
+    int bc[2] = {0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (has && cn >= 0) {
+            const NdNodeDev ch = A.nodes[cn];
+            bc[ci] = ch.b;
+            Uc[ci] = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
+        }
+    }
+    for (int e = tid; e < 2 * 128; e += 256) {
+        const int ci = e >> 7, r = e & 127;
+        iv[e] = (has && bc[ci] > 0 && r < f) ? A.inv[v.inv_off + ci * f + r] : -1;
+    }
+    for (int e = tid; e < ld * 16 + 16; e += 256) S[e] = 0.0;
+    __syncthreads();
+    for (int k = p + tid; k < 16; k += 256) S[k + ld * k] = 1.0;    // identity padding of the pivot block
+    {   // matrix entries of this front (unique targets, all in pivot columns)
+        const double* pl = A.planes + (size_t)img * A.n;
+        for (int e = tid; e < v.orig_cnt; e += 256) {
+            const int4 o = A.orig[v.orig_off + e];
+            const int r = o.x < p ? o.x : o.x + sh;
+            S[r + ld * o.y] += pl[(size_t)(o.z & 15) * A.tot + o.w];
+        }
+    }
+    __syncthreads();
+    // the children's entries of the pivot columns: child 0, then child 1 (panel entry (R, c), R >= c, c < p)
+    for (int e0 = 0; e0 < f * p; e0 += 256 * 4) {
+        double g[4][2];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u + tid, f * p - 1);
+            cc[u] = e / f; rr[u] = e - cc[u] * f;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = iv[ci * 128 + rr[u]], c = iv[ci * 128 + cc[u]];
+                const bool ok = a >= 0 && c >= 0 && rr[u] >= cc[u];
+                g[u][ci] = Uc[ci][ok ? a + bc[ci] * c : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + 256 * u + tid >= f * p || rr[u] < cc[u]) continue;
+            double* t = S + (rr[u] < p ? rr[u] : rr[u] + sh) + ld * cc[u];
+            double x = *t;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const bool ok = iv[ci * 128 + rr[u]] >= 0 && iv[ci * 128 + cc[u]] >= 0;
+                if (ok) x += g[u][ci];
+            }
+            *t = x;
+        }
+    }
+    __syncthreads();
+    // update-matrix tiles (i, j), 1 <= j <= i < P, dealt to the waves; wave 0 factors the panel first
+    const int m = P - 1, ntile = m * (m + 1) / 2;
+    auto tile_of = [&](int t, int& i, int& j) {
+        int a = 0, c = t;
+        while (c > a) { c -= a + 1; ++a; }
+        i = 1 + a; j = 1 + c;
+    };
+    auto request = [&](int t, double (&g)[4][2]) {
+        int i, j;
+        tile_of(min(t, ntile - 1), i, j);
+        const int C = 16 * j + lr - sh;                              // front row / column indices
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = R < f ? iv[ci * 128 + R] : -1, c = C < f ? iv[ci * 128 + C] : -1;
+                g[q][ci] = Uc[ci][(a >= 0 && c >= 0 && R >= C) ? a + bc[ci] * c : 0];
+            }
+        }
+    };
+    double gq[4][2];
+    const int t0 = wave == 0 ? 3 : wave - 1;                         // wave 0 joins after the factorisation
+    if (t0 < ntile) request(t0, gq);
+    bool bad = false;
+    if (wave == 0) {
+        if (MP > 64) bad = bcr_panel_factor<true>(S, ld, MP, 0, lane, dinv, p);
+        else bad = bcr_panel_factor<false>(S, ld, MP, 0, lane, dinv, p);
+        if (bad && lane == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    }
+    __syncthreads();
+    if (wave == 0) bcr_tile_inverse(S, ld, lane, dinv);
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    for (int t = t0; t < ntile; t += 4) {
+        int i, j;
+        tile_of(t, i, j);
+        const int C = 16 * j + lr - sh;
+        bcr_d4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+            double x = 0.0;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = R < f ? iv[ci * 128 + R] : -1, c = C < f ? iv[ci * 128 + C] : -1;
+                if (a >= 0 && c >= 0 && R >= C) x += gq[q][ci];
+            }
+            acc[q] = x;
+        }
+        if (t + 4 < ntile) request(t + 4, gq);                       // the next tile's entries fly during this tile's products
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double x = S[(16 * i + lr) + ld * (4 * kk + lk)];
+            const double y = S[(16 * j + lr) + ld * (4 * kk + lk)];
+            acc = bcr_mfma(-x, y, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+            if (R < f && C < f && R >= C) U[(R - p) + (size_t)b * (C - p)] = acc[q];
+        }
+    }
+    __syncthreads();                                                // wave 0's inverse before the factor columns go out
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    for (int c = wave; c < p; c += 4)
+        for (int r = lane; r < f; r += 64) {
+            double x;
+            if (r < p) x = (r >= c) ? S[r + ld * c] : 0.0;
+            else x = S[(r + sh) + ld * c];
+            fc[r + (size_t)f * c] = x;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // small regime, one WAVE per front: f <= F <= 64 rows (one per lane), p <= P <= 32 pivots
 // ------------------------------------------------------------------------------------------------------------------
 // The bottom levels of the tree are hundreds of thousands of fronts of a few dozen rows; nd_front_small_kernel spends

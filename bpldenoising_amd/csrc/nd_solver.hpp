@@ -33,6 +33,7 @@ struct NdSolver {
         bool has_child = false;
         long long fac0 = 0, fac_len = 0, ws_len = 0;
         int wave = -1;                 // >= 0: instance of nd_front_wave_kernel (a wave per front) that holds every front of the level
+        bool skinny = false;           // <= 16 pivots and <= 128 rows, with children: nd_front_skinny_kernel (only the pivot block column in LDS)
     };
     std::vector<Level> lv;
     bool built = false;
@@ -47,6 +48,7 @@ struct NdSolver {
     std::string err;
     double factor_flop = 0.0;          // per image (multiply-add = 2)
     bool wave_fronts = true;           // Cholesky, fronts of <= 64 rows and <= 32 pivots: nd_front_wave_kernel (false: tools, A/B timing)
+    bool skinny_fronts = true;         // Cholesky, levels of fronts with <= 16 pivots that are too tall for the wave kernel: nd_front_skinny_kernel
     bool staged_solve = true;          // small levels with f p <= NDS_STAGE: substitutions with the factor block staged in LDS
 
     // the instances of nd_front_wave_kernel<F, P>, smallest first within a pivot class
@@ -114,6 +116,7 @@ struct NdSolver {
             // other there; wider pivot blocks (the root of a 128-wide image) go through bcr_potrf_lds_body (large regime)
             a.small = a.MPmax <= 128 && a.pmax <= 48;
             if (a.small && !lu) a.wave = pick_wave(a.fmax, a.pmax);
+            a.skinny = a.small && !lu && a.wave < 0 && a.has_child && a.pmax <= 16 && 16 + nd_up16(a.bmax) <= 128;
         }
         std::vector<NdNodeDev> nd(T.nodes.size());
         for (size_t q = 0; q < T.nodes.size(); ++q) {
@@ -123,7 +126,7 @@ struct NdSolver {
         // parent -> child maps of the large-regime fronts (gather-form assembly, nd_gather_kernel)
         std::vector<int> inv;
         for (int l = 0; l < L; ++l) {
-            if (lv[l].small) continue;
+            if (lv[l].small && !lv[l].skinny) continue;
             for (int q = lv[l].n0; q < lv[l].n1; ++q) {
                 const NdNode& v = T.nodes[q];
                 if (v.child[0] < 0 && v.child[1] < 0) continue;
@@ -227,7 +230,9 @@ struct NdSolver {
             const int cnt = a.n1 - a.n0;
             if (a.small) {
                 A.node0 = a.n0;
-                if (wave_fronts && a.wave >= 0) {
+                if (skinny_fronts && a.skinny) {
+                    hipLaunchKernelGGL(nd_front_skinny_kernel, dim3(cnt, nimg), dim3(256), nd_skinny_lds(16 + nd_up16(a.bmax)), stream, A);
+                } else if (wave_fronts && a.wave >= 0) {
                     int n;
                     hipLaunchKernelGGL(wave_insts(n)[a.wave].fn, dim3(cnt, nimg), dim3(64), 0, stream, A);
                 } else if (a.MPmax <= 48) hipLaunchKernelGGL((nd_front_small_kernel<false, 128>), dim3(cnt, nimg), dim3(128), nd_small_lds(a.MPmax), stream, A);

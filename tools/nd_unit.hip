@@ -203,6 +203,7 @@ static int timing(int M, int nimg, bool sr, int leaf) {
     auto t0 = std::chrono::steady_clock::now();
     if (S.build(M, M, st, leaf)) { printf("build failed: %s\n", S.err.c_str()); return 1; }
     if (getenv("ND_NO_STAGE")) S.staged_solve = false;  // A/B: the column-loop substitutions on every small level
+    if (getenv("ND_NO_SKINNY")) S.skinny_fronts = false;
     if (getenv("ND_NO_WAVE")) S.wave_fronts = false;    // A/B: the workgroup-per-front kernel on every small level (this tool only)
     {
         int nw = 0, ns = 0;
