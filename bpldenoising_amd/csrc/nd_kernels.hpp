@@ -400,6 +400,203 @@ __global__ __launch_bounds__(256, 3) void nd_front_skinny_kernel(NdArgs A) {
         }
 }
 
+// The same for fronts of 17 .. 32 pivots and up to 256 rows (1024^2: the two lowest levels of the large regime, 12 288 fronts per
+// eight images, which cost five launches per level -- gather, matrix entries, potrf, trsm, Schur -- and three passes over
+// their update matrices): TWO pivot block columns in LDS (MP x 32, <= 58 KB).  Block column 0 is factored by wave 0 for its
+// first 64 rows (bcr_panel_factor) and by one thread per row below them (the row-wise pass bcr_panel_factor itself uses for
+// rows 64 ..), block column 1 receives -L(:, 0) L(1, 0)^T on the MFMA and is factored the same way; W = L11^-1 (two tile
+// inverses and one off-diagonal tile) is formed by wave 0 while the other waves already produce update-matrix tiles:
+// gathered children's entries as the accumulator, minus two block columns of products.
+// grid (fronts of the level, nimg), block 256; dynamic LDS nd_skinny2_lds(MPmax).
+inline size_t nd_skinny2_lds(int MP) { return sizeof(double) * ((size_t)(MP + 1) * 32 + 32) + sizeof(int) * 2 * 256; }
+
+// rows 16 pc + 64 .. MP - 1 of block column pc against its finished diagonal tile (strictly lower entries L(q, c) in the tile,
+// 1 / l_cc in dinv): right-looking over the 16 columns, one thread per row -- the arithmetic of bcr_panel_factor<true>'s second half
+__device__ __forceinline__ void nd_panel_rows_below(double* __restrict__ S, int ld, int MP, int pc, const double* __restrict__ dinv, int tid, int nthr) {
+    const double* Lt = S + 16 * pc + ld * (16 * pc);
+    for (int r = 16 * pc + 64 + tid; r < MP; r += nthr) {
+        double m[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) m[c] = S[r + ld * (16 * pc + c)];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            m[c] *= dinv[16 * pc + c];
+#pragma unroll
+            for (int q = c + 1; q < 16; ++q) m[q] = __builtin_fma(-m[c], Lt[q + ld * c], m[q]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[r + ld * (16 * pc + c)] = m[c];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nd_front_skinny2_kernel(NdArgs A) {
+    extern __shared__ double S[];
+    const int node = A.node0 + blockIdx.x, img = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const NdNodeDev v = A.nodes[node];
+    const int p = v.p, b = v.b, f = p + b, sh = 32 - p;              // boundary row i of the front sits at panel row 32 + i
+    const int MP = 32 + nd_up16(b), ld = MP + 1, P = MP >> 4;
+    double* dinv = S + (size_t)ld * 32;
+    int* iv = reinterpret_cast<int*>(dinv + 32);                     // iv[ci * 256 + front row]: index in child ci's boundary, or -1
+    const bool has = v.inv_off >= 0;
+    const double* Uc[2] = {A.ws_child, A.ws_child};
+    int bc[2] = {0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int cn = ci ? v.child1 : v.child0;
+        if (has && cn >= 0) {
+            const NdNodeDev ch = A.nodes[cn];
+            bc[ci] = ch.b;
+            Uc[ci] = A.ws_child + (size_t)img * A.ws_child_stride + ch.u_off;
+        }
+    }
+    for (int e = tid; e < 2 * 256; e += 256) {
+        const int ci = e >> 8, r = e & 255;
+        iv[e] = (has && bc[ci] > 0 && r < f) ? A.inv[v.inv_off + ci * f + r] : -1;
+    }
+    for (int e = tid; e < ld * 32 + 32; e += 256) S[e] = 0.0;
+    __syncthreads();
+    for (int k = p + tid; k < 32; k += 256) S[k + ld * k] = 1.0;    // identity padding of the pivot block
+    {   // matrix entries of this front (unique targets, all in pivot columns)
+        const double* pl = A.planes + (size_t)img * A.n;
+        for (int e = tid; e < v.orig_cnt; e += 256) {
+            const int4 o = A.orig[v.orig_off + e];
+            const int r = o.x < p ? o.x : o.x + sh;
+            S[r + ld * o.y] += pl[(size_t)(o.z & 15) * A.tot + o.w];
+        }
+    }
+    __syncthreads();
+    // the children's entries of the pivot columns: child 0, then child 1 (panel entry (R, c), R >= c, c < p)
+    for (int e0 = 0; e0 < f * p; e0 += 256 * 4) {
+        double g[4][2];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u + tid, f * p - 1);
+            cc[u] = e / f; rr[u] = e - cc[u] * f;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = iv[ci * 256 + rr[u]], c = iv[ci * 256 + cc[u]];
+                const bool ok = a >= 0 && c >= 0 && rr[u] >= cc[u];
+                g[u][ci] = Uc[ci][ok ? a + bc[ci] * c : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + 256 * u + tid >= f * p || rr[u] < cc[u]) continue;
+            double* t = S + (rr[u] < p ? rr[u] : rr[u] + sh) + ld * cc[u];
+            double x = *t;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const bool ok = iv[ci * 256 + rr[u]] >= 0 && iv[ci * 256 + cc[u]] >= 0;
+                if (ok) x += g[u][ci];
+            }
+            *t = x;
+        }
+    }
+    __syncthreads();
+    // update-matrix tiles (i, j), 2 <= j <= i < P
+    const int m = P - 2, ntile = m * (m + 1) / 2;
+    auto tile_of = [&](int t, int& i, int& j) {
+        int a = 0, c = t;
+        while (c > a) { c -= a + 1; ++a; }
+        i = 2 + a; j = 2 + c;
+    };
+    auto request = [&](int t, double (&g)[4][2]) {
+        int i, j;
+        tile_of(min(t, ntile - 1), i, j);
+        const int C = 16 * j + lr - sh;                              // front row / column indices
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = R < f ? iv[ci * 256 + R] : -1, c = C < f ? iv[ci * 256 + C] : -1;
+                g[q][ci] = Uc[ci][(a >= 0 && c >= 0 && R >= C) ? a + bc[ci] * c : 0];
+            }
+        }
+    };
+    double gq[4][2];
+    const int t0 = wave == 0 ? 3 : wave - 1;                         // wave 0 joins after the inverse of the pivot block
+    if (ntile > 0 && t0 < ntile) request(t0, gq);
+    bool bad = false;
+    // block column 0: first 64 rows by wave 0, the rows below them one thread each
+    if (wave == 0) bad |= bcr_panel_factor<false>(S, ld, min(MP, 64), 0, lane, dinv, min(p, 16));
+    __syncthreads();
+    nd_panel_rows_below(S, ld, MP, 0, dinv, tid, 256);
+    __syncthreads();
+    // block column 1 receives block column 0 (left-looking), then the same
+    for (int i = 1 + wave; i < P; i += 4) {
+        bcr_d4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = S[(16 * i + lk + 4 * q) + ld * (16 + lr)];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double x = S[(16 * i + lr) + ld * (4 * kk + lk)];
+            const double y = S[(16 + lr) + ld * (4 * kk + lk)];
+            acc = bcr_mfma(-x, y, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(16 * i + lk + 4 * q) + ld * (16 + lr)] = acc[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bad |= bcr_panel_factor<false>(S, ld, min(MP, 80), 1, lane, dinv, p - 16);
+        if (bad && lane == 0 && A.fail[img] == 0) A.fail[img] = node + 1;
+    }
+    __syncthreads();
+    nd_panel_rows_below(S, ld, MP, 1, dinv, tid, 256);
+    __syncthreads();
+    if (wave == 0) {   // W = L11^-1: the two diagonal tiles, then tile (1, 0) into the upper tile (0, 1)
+        bcr_tile_inverse(S, ld, lane, dinv);
+        bcr_tile_inverse(S + 16 + ld * 16, ld, lane, dinv + 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bcr_winv_tile(S, ld, 1, 0, lr, lk);
+    }
+    double* U = A.ws_mine + (size_t)img * A.ws_mine_stride + v.u_off;
+    for (int t = t0; t < ntile; t += 4) {
+        int i, j;
+        tile_of(t, i, j);
+        const int C = 16 * j + lr - sh;
+        bcr_d4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+            double x = 0.0;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int a = R < f ? iv[ci * 256 + R] : -1, c = C < f ? iv[ci * 256 + C] : -1;
+                if (a >= 0 && c >= 0 && R >= C) x += gq[q][ci];
+            }
+            acc[q] = x;
+        }
+        if (t + 4 < ntile) request(t + 4, gq);                       // the next tile's entries fly during this tile's products
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double x = S[(16 * i + lr) + ld * (16 * qq + 4 * kk + lk)];
+                const double y = S[(16 * j + lr) + ld * (16 * qq + 4 * kk + lk)];
+                acc = bcr_mfma(-x, y, acc);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = 16 * i + lk + 4 * q - sh;
+            if (R < f && C < f && R >= C) U[(R - p) + (size_t)b * (C - p)] = acc[q];
+        }
+    }
+    __syncthreads();                                                // wave 0's inverse before the factor columns go out
+    double* fc = A.fac + (size_t)img * A.fac_stride + v.fac_off;
+    for (int c = wave; c < p; c += 4)
+        for (int r = lane; r < f; r += 64) {
+            double x;
+            if (r < p) x = (r >= c) ? S[(16 * (c >> 4) + (r & 15)) + ld * (16 * (r >> 4) + (c & 15))] : 0.0;
+            else x = S[(r + sh) + ld * c];
+            fc[r + (size_t)f * c] = x;
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // small regime, one WAVE per front: f <= F <= 64 rows (one per lane), p <= P <= 32 pivots
 // ------------------------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ struct NdSolver {
         long long fac0 = 0, fac_len = 0, ws_len = 0;
         int wave = -1;                 // >= 0: instance of nd_front_wave_kernel (a wave per front) that holds every front of the level
         bool skinny = false;           // <= 16 pivots and <= 128 rows, with children: nd_front_skinny_kernel (only the pivot block column in LDS)
+        bool skinny2 = false;          // large-regime level of fronts with <= 32 pivots and <= 256 rows: nd_front_skinny2_kernel (two block columns)
     };
     std::vector<Level> lv;
     bool built = false;
@@ -117,6 +118,7 @@ struct NdSolver {
             a.small = a.MPmax <= 128 && a.pmax <= 48;
             if (a.small && !lu) a.wave = pick_wave(a.fmax, a.pmax);
             a.skinny = a.small && !lu && a.wave < 0 && a.has_child && a.pmax <= 16 && 16 + nd_up16(a.bmax) <= 128;
+            a.skinny2 = !a.small && !lu && a.has_child && a.pmax <= 32 && 32 + nd_up16(a.bmax) <= 256;
         }
         std::vector<NdNodeDev> nd(T.nodes.size());
         for (size_t q = 0; q < T.nodes.size(); ++q) {
@@ -154,6 +156,8 @@ struct NdSolver {
         NDCHK(hipMemcpy(d_orig, T.orig.data(), T.orig.size() * sizeof(int4), hipMemcpyHostToDevice));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_small_kernel<true, NDS_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)nd_small_lds(128)));
+        NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_skinny2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)nd_skinny2_lds(256)));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_potrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)bcr_potrf_lds(HB2_NB)));
         NDCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nd_front_small_lu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -238,6 +242,11 @@ struct NdSolver {
                 } else if (a.MPmax <= 48) hipLaunchKernelGGL((nd_front_small_kernel<false, 128>), dim3(cnt, nimg), dim3(128), nd_small_lds(a.MPmax), stream, A);
                 else if (a.MPmax <= 64) hipLaunchKernelGGL((nd_front_small_kernel<false, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 else hipLaunchKernelGGL((nd_front_small_kernel<true, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
+                continue;
+            }
+            if (skinny_fronts && a.skinny2) {
+                A.node0 = a.n0;
+                hipLaunchKernelGGL(nd_front_skinny2_kernel, dim3(cnt, nimg), dim3(256), nd_skinny2_lds(32 + nd_up16(a.bmax)), stream, A);
                 continue;
             }
             for (int q0 = a.n0; q0 < a.n1; q0 += 32768) {     // grid.y <= 65535
