@@ -258,6 +258,8 @@ struct HandleOptions {
     int sr_force_lu = 0;              // 1: the LU variant of the nested dissection on the symmetric sum-of-regularisers systems too
     int nd_leaf = 0;                  // > 0: leaf size (pixels) of the nested-dissection tree; 0 = 32
     int nd_wave = 1;                  // 0: the workgroup-per-front kernel on every small level (cross-check of nd_front_wave_kernel)
+    int nd_skinny = 1;                // 0: fronts of <= 32 pivots through nd_front_small_kernel / the large-regime kernels (cross-check of nd_front_skinny*_kernel)
+    int nd_staged = 1;                // 0: substitutions of the small levels by the column-loop kernels (cross-check of nd_*_staged_kernel: same bits)
     int hb_sync = 0;                  // HBM band cross-check solver: 0 automatic, 1 HIP events, 2 stream memory operations (fails if unavailable)
     int hb_single_stream = 0;         // ... 1: its three streams folded into one (rocprofv3 --pmc)
     int hb_rw = 0;                    // ... 32 / 128: row width of its trailing update (0 automatic)
@@ -1099,6 +1101,8 @@ int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, in
     rc = nd.alloc(*Oc, h->stream);
     if (rc) return set_err(h, rc, "adjoint gradient (%s): %s", what, nd.err.c_str());
     nd.wave_fronts = h->opt.nd_wave != 0;
+    nd.skinny_fronts = h->opt.nd_skinny != 0;
+    nd.staged_solve = h->opt.nd_staged != 0;
     return BPLTV_OK;
 }
 
@@ -2937,6 +2941,10 @@ int bpltv_set_option(bpltv_t* h, const char* name, double value) {
         h->opt.nd_leaf = iv;
     } else if (nm == "nd_wave") {
         h->opt.nd_wave = iv ? 1 : 0;
+    } else if (nm == "nd_skinny") {
+        h->opt.nd_skinny = iv ? 1 : 0;
+    } else if (nm == "nd_staged") {
+        h->opt.nd_staged = iv ? 1 : 0;
     } else if (nm == "hb_sync" || nm == "hb_single_stream" || nm == "hb_rw") {
         if (nm == "hb_sync" && (iv < 0 || iv > 2)) return set_err(h, BPLTV_E_ARG, "set_option(hb_sync): 0 automatic, 1 events, 2 stream memory operations");
         if (nm == "hb_rw" && iv != 0 && iv != 32 && iv != 128) return set_err(h, BPLTV_E_ARG, "set_option(hb_rw): 0, 32 or 128");

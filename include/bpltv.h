@@ -294,6 +294,9 @@ int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const b
  *   "nd_leaf"            leaf size in pixels of the nested-dissection tree (0 = 32)
  *   "nd_wave"            0: fronts of <= 64 rows are factored by the workgroup-per-front kernel like the larger small fronts
  *                        (cross-check of the wave-per-front kernel, which is the default: 1)
+ *   "nd_skinny"          0: fronts of <= 32 pivots that keep only their pivot block columns in LDS go through the older
+ *                        kernels instead (cross-check; default 1)
+ *   "nd_staged"          0: substitutions of the small levels by the column-loop kernels (cross-check: the same bits; default 1)
  *   "hb_sync"            HBM band cross-check solver (params.reserved[4] = 1): 0 automatic, 1 HIP events (what a
  *                        rocprofv3 run needs), 2 stream memory operations (BPLTV_E_HIP when the device has none)
  *   "hb_single_stream"   1: that solver's three streams folded into one (rocprofv3 --pmc)

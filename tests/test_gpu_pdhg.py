@@ -438,5 +438,12 @@ def test_parameter_resident_in_hbm_and_handle_options(gpu_solver_cls):
     _, _, gwg = s.evaluate(0.1, 0.1, maxiter=150)
     s.set_option("nd_wave", 1)
     assert np.isclose(gwg, g32, rtol=1e-9) and s.evaluate(0.1, 0.1, maxiter=150)[2] == g32
+    s.set_option("nd_staged", 0)                                             # column-loop substitutions: the same bits
+    assert s.evaluate(0.1, 0.1, maxiter=150)[2] == g32
+    s.set_option("nd_staged", 1)
+    s.set_option("nd_skinny", 0)                                             # skinny fronts by the older kernels
+    _, _, gsk = s.evaluate(0.1, 0.1, maxiter=150)
+    s.set_option("nd_skinny", 1)
+    assert np.isclose(gsk, g32, rtol=1e-9) and s.evaluate(0.1, 0.1, maxiter=150)[2] == g32
     s.close()
 
