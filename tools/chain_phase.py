@@ -43,7 +43,7 @@ def describe(tag, r):
     dA, dB = np.diff(A), np.diff(B[1:])
     print("%s step %.3f ms: chain 0 period mean %.2f us (min %.2f max %.2f), chain 1 %.2f us; chain 1 starts %.1f us after chain 0" % (tag, ms_, dA.mean(), dA.min(), dA.max(), dB.mean(), B[0] - t0))
     # phase of chain 1's launch k+1 (full launches) inside chain 0's period, sampled along the sequence
-    for k0 in (2, 20, 100, 300, 500, 600):
+    for k0 in (0, 8, 16, 24, 32, 40, 48, 100, 150, 160, 170, 300, 500, 600):
         k = np.arange(k0, min(k0 + 8, len(A) - 1))
         ph = []
         for kk in k:
@@ -58,6 +58,8 @@ slow = max(res, key=lambda r: r[0])
 describe("fast", fast)
 if slow[0] > 1.1 * fast[0]:
     describe("slow", slow)
+    for r in [r for r in res if r[0] > 1.03 * fast[0]][:6]:
+        describe("slow-ish", r)
     sl = [r for r in res if r[0] > 1.1 * fast[0]]
     print("start offsets (chain 1 - chain 0, us) of the slow steps: %s" % " ".join("%.1f" % (r[2][0] - r[1][0]) for r in sl))
 print("start offsets of the fast steps: %s" % " ".join("%.1f" % (r[2][0] - r[1][0]) for r in res if r[0] <= 1.1 * fast[0]))
