@@ -259,6 +259,7 @@ struct HandleOptions {
     int nd_leaf = 0;                  // > 0: leaf size (pixels) of the nested-dissection tree; 0 = 32
     int nd_wave = 1;                  // 0: the workgroup-per-front kernel on every small level (cross-check of nd_front_wave_kernel)
     int nd_skinny = 1;                // 0: fronts of <= 32 pivots through nd_front_small_kernel / the large-regime kernels (cross-check of nd_front_skinny*_kernel)
+    int nd_skinny_min = -1, nd_skinny2_min = -1;   // >= 0: (front, image) pairs a level needs for those kernels (-1: the defaults below)
     int nd_staged = 1;                // 0: substitutions of the small levels by the column-loop kernels (cross-check of nd_*_staged_kernel: same bits)
     int hb_sync = 0;                  // HBM band cross-check solver: 0 automatic, 1 HIP events, 2 stream memory operations (fails if unavailable)
     int hb_single_stream = 0;         // ... 1: its three streams folded into one (rocprofv3 --pmc)
@@ -1102,6 +1103,8 @@ int nd_alloc(bpltv_t* h, NdSolver& nd, const NdStencil& st, const char* what, in
     if (rc) return set_err(h, rc, "adjoint gradient (%s): %s", what, nd.err.c_str());
     nd.wave_fronts = h->opt.nd_wave != 0;
     nd.skinny_fronts = h->opt.nd_skinny != 0;
+    nd.skinny_min = h->opt.nd_skinny_min >= 0 ? h->opt.nd_skinny_min : 0;
+    nd.skinny2_min = h->opt.nd_skinny2_min >= 0 ? h->opt.nd_skinny2_min : 256;   // 10 x 128^2: its levels of 160 / 80 fronts lose 4 %, 40 x 128^2 (640 / 320) gains
     nd.staged_solve = h->opt.nd_staged != 0;
     return BPLTV_OK;
 }
@@ -2943,6 +2946,10 @@ int bpltv_set_option(bpltv_t* h, const char* name, double value) {
         h->opt.nd_wave = iv ? 1 : 0;
     } else if (nm == "nd_skinny") {
         h->opt.nd_skinny = iv ? 1 : 0;
+    } else if (nm == "nd_skinny_min") {
+        h->opt.nd_skinny_min = iv;
+    } else if (nm == "nd_skinny2_min") {
+        h->opt.nd_skinny2_min = iv;
     } else if (nm == "nd_staged") {
         h->opt.nd_staged = iv ? 1 : 0;
     } else if (nm == "hb_sync" || nm == "hb_single_stream" || nm == "hb_rw") {

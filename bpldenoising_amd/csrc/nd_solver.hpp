@@ -50,6 +50,8 @@ struct NdSolver {
     double factor_flop = 0.0;          // per image (multiply-add = 2)
     bool wave_fronts = true;           // Cholesky, fronts of <= 64 rows and <= 32 pivots: nd_front_wave_kernel (false: tools, A/B timing)
     bool skinny_fronts = true;         // Cholesky, levels of fronts with <= 16 pivots that are too tall for the wave kernel: nd_front_skinny_kernel
+    int skinny_min = 0, skinny2_min = 256; // ... only on levels of at least so many (front, image) pairs: one launch with a long serial chain per
+                                       // front against five short launches pays once the level fills the chip (bpltv.hip sets the measured thresholds)
     bool staged_solve = true;          // small levels with f p <= NDS_STAGE: substitutions with the factor block staged in LDS
 
     // the instances of nd_front_wave_kernel<F, P>, smallest first within a pivot class
@@ -234,7 +236,7 @@ struct NdSolver {
             const int cnt = a.n1 - a.n0;
             if (a.small) {
                 A.node0 = a.n0;
-                if (skinny_fronts && a.skinny) {
+                if (skinny_fronts && a.skinny && (long long)cnt * nimg >= skinny_min) {
                     hipLaunchKernelGGL(nd_front_skinny_kernel, dim3(cnt, nimg), dim3(256), nd_skinny_lds(16 + nd_up16(a.bmax)), stream, A);
                 } else if (wave_fronts && a.wave >= 0) {
                     int n;
@@ -244,7 +246,7 @@ struct NdSolver {
                 else hipLaunchKernelGGL((nd_front_small_kernel<true, NDS_T>), dim3(cnt, nimg), dim3(NDS_T), nd_small_lds(a.MPmax), stream, A);
                 continue;
             }
-            if (skinny_fronts && a.skinny2) {
+            if (skinny_fronts && a.skinny2 && (long long)cnt * nimg >= skinny2_min) {
                 A.node0 = a.n0;
                 hipLaunchKernelGGL(nd_front_skinny2_kernel, dim3(cnt, nimg), dim3(256), nd_skinny2_lds(32 + nd_up16(a.bmax)), stream, A);
                 continue;

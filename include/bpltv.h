@@ -296,6 +296,8 @@ int bpltv_sweep(bpltv_t *h, const double *alphas, int K, int am, int an, const b
  *                        (cross-check of the wave-per-front kernel, which is the default: 1)
  *   "nd_skinny"          0: fronts of <= 32 pivots that keep only their pivot block columns in LDS go through the older
  *                        kernels instead (cross-check; default 1)
+ *   "nd_skinny_min", "nd_skinny2_min"   (front, image) pairs a level needs before those two kernels take it (defaults 0 / 256:
+ *                        below that the five short launches of the large regime finish a level sooner than one long one)
  *   "nd_staged"          0: substitutions of the small levels by the column-loop kernels (cross-check: the same bits; default 1)
  *   "hb_sync"            HBM band cross-check solver (params.reserved[4] = 1): 0 automatic, 1 HIP events (what a
  *                        rocprofv3 run needs), 2 stream memory operations (BPLTV_E_HIP when the device has none)
