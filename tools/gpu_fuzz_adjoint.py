@@ -2,7 +2,7 @@
 """Developer probe: random shapes through evaluate() against the oracle's gradient -- every adjoint path (nested
 dissection = the automatic choice, block cyclic reduction, LDS band, HBM band incl. twisted / odd bandwidth / ragged
 last panel), both branches, all parameter kinds, with and without forced image groups.
-usage: gpu_fuzz_adjoint.py [cases] [seed]"""
+usage: gpu_fuzz_adjoint.py [cases] [seed] [all-kernels]   (all-kernels: nd_front_skinny2_kernel on every eligible level, whatever the batch size)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,6 +35,7 @@ for case in range(cases):
     ub, f = synth_batch(O, N, M, seed=int(rng.integers(1, 10000)))
     meth = str(rng.choice(["auto", "auto", "band", "bcr" if (M <= 128 and N >= 2) else "nd"]))
     s = TVSolver(M, N, O); s.set_data(ub, f)
+    if "all-kernels" in sys.argv: s.set_option("nd_skinny2_min", 0)
     if meth in ("auto", "nd") and O > 1 and rng.random() < 0.3:
         s.set_option("adjoint_budget_mb", 1.3 * 8e-6 * 40 * M * N * max(4, np.log2(M * N)))   # a group of about one image
     try:

@@ -28,6 +28,7 @@ static int check(int M, int N, bool sr, int leaf, int nimg, double big) {
     NdSolver S;
     const NdStencil st = sr ? nd_stencil_sr() : nd_stencil_tv();
     if (S.build(M, N, st, leaf)) { printf("build failed: %s\n", S.err.c_str()); return 1; }
+    S.skinny2_min = 0;   // every kernel the tree is eligible for, whatever the number of images (the library waits for 256 fronts per level)
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
     if (S.alloc(nimg, stream)) { printf("alloc failed: %s\n", S.err.c_str()); return 1; }
