@@ -550,6 +550,30 @@ def test_hbm_pipeline_event_and_value_waits_agree(gpu_solver_cls, monkeypatch):
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
 
 
+def test_skinny_fronts_whatever_the_batch_size(gpu_solver_cls):
+    """nd_front_skinny2_kernel (fronts of 17..32 pivots with two pivot block columns in LDS) takes a level only from 256
+    (front, image) pairs on; option "nd_skinny2_min" = 0 sends the 32 such fronts of two 150 x 139 images through it: the
+    same gradient as the large-regime kernels to 1e-9 (another order of the same operations), the same quality gate, and
+    against the oracle like every other path."""
+    from oracle import c_oracle as co
+    O, N, M = 2, 139, 150
+    ub, f = synth_batch(O, N, M, seed=139)
+    alpha = 0.04 + 0.1 * np.random.default_rng(3).random((N, M))
+    s = gpu_solver_cls(M, N, O)
+    s.set_data(ub, f)
+    u0, c0, g0 = s.evaluate(alpha, 0.1, maxiter=300)
+    r0 = s.stats()["adjoint_residual"]
+    s.set_option("nd_skinny2_min", 0)
+    u1, c1, g1 = s.evaluate(alpha, 0.1, maxiter=300)
+    st = s.stats()
+    assert np.array_equal(u0, u1) and c0 == c1 and st["adjoint_method"] == "nd"
+    assert np.allclose(g1, g0, rtol=1e-9, atol=1e-12 * np.abs(g0).max()) and st["adjoint_residual"] < 1e-8 and r0 < 1e-8
+    s.set_option("nd_skinny", 0)            # and none of the skinny kernels at all
+    _, _, g2 = s.evaluate(alpha, 0.1, maxiter=300)
+    assert np.allclose(g2, g0, rtol=1e-9, atol=1e-12 * np.abs(g0).max())
+    s.close()
+
+
 def test_nd_solver_unit_checks(gpu_solver_cls):
     """tools/nd_unit.hip: the nested-dissection Cholesky (fronts in LDS, fronts in HBM with multi-panel pivot blocks,
     gather-form substitutions) against the host restatement tools/nd_ref.hpp: factor entries and solutions on random
