@@ -91,6 +91,16 @@ void launch_rows_variant(const PdhgArgs& a, int grid, hipStream_t s) {
       reinterpret_cast<const void*>(&pdhg_rows_kernel<double, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL),  \
       "rows_64x" #PJ "px_" #TJ "waves" #CL, &launch_rows_variant<float, PJ, TJ, CL>,            \
       reinterpret_cast<const void*>(&pdhg_rows_kernel<float, PJ, TJ, CL>), pdhg_rows_lds(PJ, TJ, CL, sizeof(float)), 1, 1 }
+// rows of 128 pixels, two waves side by side (pdhg_rowsw_kernel): region 128 x (PJ * TJ), 128 * TJ threads
+template <typename T, int PJ, int TJ>
+void launch_rowsw_variant(const PdhgArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pdhg_rowsw_kernel<T, PJ, TJ>), pdhg_grid(a, grid), dim3(128 * TJ), pdhg_rowsw_lds(PJ, TJ, sizeof(T)), s, a);
+}
+#define VARRW(PJ, TJ)                                                                           \
+    { 128, PJ * TJ, 128 * TJ, &launch_rowsw_variant<double, PJ, TJ>,                            \
+      reinterpret_cast<const void*>(&pdhg_rowsw_kernel<double, PJ, TJ>), pdhg_rowsw_lds(PJ, TJ), \
+      "rows_128x" #PJ "px_" #TJ "strips", &launch_rowsw_variant<float, PJ, TJ>,                 \
+      reinterpret_cast<const void*>(&pdhg_rowsw_kernel<float, PJ, TJ>), pdhg_rowsw_lds(PJ, TJ, sizeof(float)), 1, 1 }
 // the same re-cut for instruction-level parallelism (pdhg_rows2_kernel): G dual chains of an interior wave in flight
 template <typename T, int PJ, int TJ, int G>
 void launch_rows2_variant(const PdhgArgs& a, int grid, hipStream_t s) {
@@ -145,6 +155,9 @@ const Variant kVariants[] = {
     VARR2(8, 8, 2),     // 31: ... two dual chains in flight
     VARS(256, 8, 4, 32, 2, 4),   // 32: streaming pipeline of 8 waves, segments of 256 rows, rings of 4 rows (76 KB of LDS), 128 VGPRs: two workgroups per CU
     VARS(256, 8, 2, 16, 2, 6),   // 33: ... rings of 2 rows (38 KB), 80 VGPRs: three workgroups per CU
+    VARRW(8, 8),        // 34: rows of 128 pixels (two waves side by side), 128x64 region, 8 px per thread, 1024 threads
+    VARRW(8, 4),        // 35: ... 128x32 region, 512 threads
+    VARRW(6, 8),        // 36: ... 128x48 region, 6 px per thread, 1024 threads
     // (round 4, 8 x 1024^2 pixel map, 480 iterations: 32 / 33 run 2.9-3.0e4 / 3.2-3.3e4 it/s against 4.1-4.2e4 of variant 19; four or
     //  six rows of prefetch (spills) 3.0e4; segments of 128 / 352 / 512 rows 3.2e4 / 3.0e4 / 2.2e4; the same pipeline fed by a
     //  loader wave through LDS-DMA 2.2-3.3e4 -- DESIGN.md section 4.1)

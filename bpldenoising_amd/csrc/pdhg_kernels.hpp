@@ -651,6 +651,181 @@ __global__ __launch_bounds__(64 * TJ) void pdhg_rows_kernel(PdhgArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// pdhg_rowsw_kernel: pdhg_rows_kernel with rows of 128 pixels -- two waves side by side (round 4).  Along i a 64-lane row
+// with its halo of 8 keeps 48 of 64 lanes (1024 columns: 21 regions, 1344 lanes); a 128-pixel row keeps 112 of 128 (9
+// regions, 1152 lanes): 14 % fewer pixel-iterations.  The two waves of a row exchange ONE column per step and direction
+// through LDS -- y1 of the left wave's lane 63 for the right wave's lane 0 (primal step), xbar of the right wave's lane 0
+// for the left wave's lane 63 (dual step) -- behind the two workgroup barriers the strips' row exchange needs anyway.
+// Same arithmetic per pixel: bit-identical results.  Block 128 * TJ (wave = 2 * strip + half), dynamic LDS pdhg_rowsw_lds.
+// ------------------------------------------------------------------------------------------
+constexpr size_t pdhg_rowsw_lds(int PJ, int TJ, size_t word = sizeof(double)) {
+    return word * (128 * 2 * (size_t)(TJ + 1) + 2 * (size_t)TJ * PJ);
+}
+
+template <typename T, int PJ, int TJ>
+__global__ __launch_bounds__(128 * TJ) void pdhg_rowsw_kernel(PdhgArgs A) {
+    constexpr int RI = 128, RJ = PJ * TJ;
+    constexpr bool CL = false;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pdhg_smem[];
+    T* sy2 = reinterpret_cast<T*>(pdhg_smem);   // [TJ + 1][128]: row tj + 1 = y2 of strip tj's last pixel row, row 0 = 0
+    T* sxb = sy2 + (TJ + 1) * 128;              // [TJ + 1][128]: row tj = xbar of strip tj's first pixel row, row TJ = 0
+    T* sE1 = sxb + (TJ + 1) * 128;              // [TJ][PJ]: y1 of lane 63 of the strip's left wave (for lane 0 of its right wave)
+    T* sEx = sE1 + TJ * PJ;                     // [TJ][PJ]: xbar of lane 0 of the right wave (for lane 63 of the left wave)
+    T* sfc = sEx;                               // (no f / alpha planes in LDS in this kernel)
+    const T* __restrict__ Axin = reinterpret_cast<const T*>(A.xin);
+    const T* __restrict__ Ay1in = reinterpret_cast<const T*>(A.y1in);
+    const T* __restrict__ Ay2in = reinterpret_cast<const T*>(A.y2in);
+    T* __restrict__ Axout = reinterpret_cast<T*>(A.xout);
+    T* __restrict__ Ay1out = reinterpret_cast<T*>(A.y1out);
+    T* __restrict__ Ay2out = reinterpret_cast<T*>(A.y2out);
+    const T* __restrict__ Af = reinterpret_cast<const T*>(A.f);
+    const int tid = threadIdx.x, l64 = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: uniform
+    const int hh = wv & 1, tj = wv >> 1;                        // left / right half of the 128-pixel row, strip
+    const int ti = l64 + 64 * hh;
+    PDHG_DECODE_BLOCK(A, imgl, ta, tb)
+    const int img = A.img0 + imgl;
+    int oi, ci0, ci1, oj, cj0, cj1;
+    tile_span(ta, A.M, RI, A.halo, oi, ci0, ci1);
+    tile_span(tb, A.N, RJ, A.halo, oj, cj0, cj1);
+    const int M = A.M, N = A.N;
+    int fimg, apar;
+    pdhg_data_image(img, A.O, A.Odata, fimg, apar);
+    const size_t base = (size_t)img * M * N;
+    const size_t fbase = (size_t)fimg * M * N;
+    const T* __restrict__ alpha = reinterpret_cast<const T*>(A.alpha) + (size_t)apar * A.astride;
+    const int amode = (A.am == 1 && A.an == 1) ? 0 : ((A.am == M && A.an == N) ? 2 : 1);
+    const bool first = (A.first != 0) || (BPLTV_DBG(A) & 1);
+    const int lj0 = PJ * tj;
+    const int gi = min(oi + ti, M - 1);
+    const bool in_i = oi + ti < M;
+
+    T x[PJ], y1[PJ], y2[PJ], f[PJ], al[PJ];
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gj = min(oj + lj0 + pj, N - 1);
+        const size_t gidx = gi + (size_t)M * gj;
+        size_t ai = 0;
+        if (amode == 2) ai = gidx;
+        else if (amode == 1) ai = ((unsigned)gi * (unsigned)A.am) / (unsigned)M + (size_t)A.am * (((unsigned)gj * (unsigned)A.an) / (unsigned)N);
+        if (!first) {
+            x[pj] = Axin[base + gidx];
+            y1[pj] = Ay1in[base + gidx];
+            y2[pj] = Ay2in[base + gidx];
+        }
+        f[pj] = Af[fbase + gidx];
+        al[pj] = alpha[ai];
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        if (first) { x[pj] = f[pj]; y1[pj] = T(0); y2[pj] = T(0); }
+        if (!(in_i && oj + lj0 + pj < N)) { f[pj] = T(0); x[pj] = T(0); y1[pj] = T(0); y2[pj] = T(0); al[pj] = T(0); }
+        if (CL) {
+            sfc[(lj0 + pj) * 128 + ti] = f[pj];
+            sfc[(RJ + lj0 + pj) * 128 + ti] = al[pj];
+        }
+    }
+    sy2[(tj + 1) * 128 + ti] = y2[PJ - 1];
+    if (tj == 0) { sy2[ti] = T(0); sxb[TJ * 128 + ti] = T(0); }
+    if (!hh && l64 == 63) {
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) sE1[tj * PJ + pj] = y1[pj];
+    }
+    __syncthreads();
+
+    const T rho = (T)A.rho;
+    const int nit = A.nit;
+    const bool hasD_last = oj + lj0 + PJ - 1 < N - 1;
+    // iterations pixel row lj is still read for: lj of them next to a near edge that is not the image border, RJ - lj
+    // next to such a far edge (see pdhg_tile_kernel)
+    int lim[PJ];
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int lj = lj0 + pj;
+        int l = nit;
+        if (oj > 0) l = min(l, lj);
+        if (oj + RJ < N) l = min(l, RJ - lj);
+        lim[pj] = l;
+    }
+    const T* __restrict__ row = reinterpret_cast<const T*>(A.tab) + (size_t)TAB_STRIDE * A.it0;
+    T tau = row[0], sigma = row[1], omega = row[2], inv1ptau = row[3], opw = row[4];
+    for (int it = 0; it < nit; ++it) {
+        const T* __restrict__ nrow = row + TAB_STRIDE * ((it + 1 < nit) ? it + 1 : it);
+        const T ntau = nrow[0], nsigma = nrow[1], nomega = nrow[2], ninv1ptau = nrow[3], nopw = nrow[4];
+        T xb[PJ];
+        // ---- primal step
+        const T y2up = sy2[tj * 128 + ti];   // y2 of the pixel row above the strip (guard row of zeros at lj = 0)
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            xb[pj] = T(0);
+            if (it < lim[pj]) {
+                T y1m = pd_lane_prev_or0(y1[pj]);                      // lane 0 of the left wave: the zero guard column
+                if (hh) { const T e_ = sE1[tj * PJ + pj]; if (l64 == 0) y1m = e_; }   // ... of the right wave: lane 63 of the left one
+                const T y2m = (pj > 0) ? y2[pj > 0 ? pj - 1 : 0] : y2up;
+                const T div = (y1m - y1[pj]) + (y2m - y2[pj]);
+                const T tt = div - (CL ? sfc[(lj0 + pj) * 128 + ti] : f[pj]);
+                const T xo = x[pj];
+                const T xn = pd_fma(-tau, tt, xo) * inv1ptau;
+                xb[pj] = pd_fma(-omega, xo, opw * xn);
+                x[pj] = xn;
+            }
+        }
+        sxb[tj * 128 + ti] = xb[0];
+        if (hh && l64 == 0) {
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) sEx[tj * PJ + pj] = xb[pj];
+        }
+        if (!(BPLTV_DBG(A) & 128)) __syncthreads();
+        // ---- dual step
+        const T xbdn = sxb[(tj + 1) * 128 + ti];   // xbar of the pixel row below the strip
+#pragma unroll
+        for (int pj = 0; pj < PJ; ++pj) {
+            if (it < lim[pj]) {
+                const T b = xb[pj];
+                T xp1 = pd_lane_next_or_self(b);                       // lane 63 of the right wave: own value
+                if (!hh) { const T e_ = sEx[tj * PJ + pj]; if (l64 == 63) xp1 = e_; }   // ... of the left wave: lane 0 of the right one
+                const T xpM = (pj < PJ - 1) ? xb[pj < PJ - 1 ? pj + 1 : pj] : (hasD_last ? xbdn : b);
+                const T d1 = xp1 - b;
+                const T d2 = xpM - b;
+                const T a = CL ? sfc[(RJ + lj0 + pj) * 128 + ti] : al[pj];
+                T y1n = pd_fma(sigma, d1, y1[pj]);
+                T y2n = pd_fma(sigma, d2, y2[pj]);
+                if (rho != T(0)) {
+                    const T den = T(1) + sigma * rho / a;
+                    y1n = y1n / den;
+                    y2n = y2n / den;
+                }
+                const T n2v = pd_fma(y2n, y2n, y1n * y1n);
+                if (n2v > a * a) {
+                    const T v = a * rsqrt_nr(n2v);
+                    y1n = y1n * v;
+                    y2n = y2n * v;
+                }
+                y1[pj] = y1n;
+                y2[pj] = y2n;
+            }
+        }
+        sy2[(tj + 1) * 128 + ti] = y2[PJ - 1];
+        if (!hh && l64 == 63) {
+#pragma unroll
+            for (int pj = 0; pj < PJ; ++pj) sE1[tj * PJ + pj] = y1[pj];
+        }
+        tau = ntau; sigma = nsigma; omega = nomega; inv1ptau = ninv1ptau; opw = nopw;
+        if (!(BPLTV_DBG(A) & 128)) __syncthreads();
+    }
+#pragma unroll
+    for (int pj = 0; pj < PJ; ++pj) {
+        const int gi2 = oi + ti, gj2 = oj + lj0 + pj;
+        if (gi2 >= ci0 && gi2 < ci1 && gj2 >= cj0 && gj2 < cj1 && !(BPLTV_DBG(A) & 2)) {
+            const size_t idx = base + gi2 + (size_t)M * gj2;
+            __hip_atomic_store(&Axout[idx], x[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay1out[idx], y1[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&Ay2out[idx], y2[pj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // pdhg_rows2_kernel: pdhg_rows_kernel re-cut for instruction-level parallelism (round 4).  Same layout (a wave = one row
 // of 64 lanes along i, PJ pixels per thread along j, DPP i-neighbours, strip ends through LDS, halo pixel rows that stop
 // early), same arithmetic per pixel (bit-identical), but:

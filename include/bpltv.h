@@ -145,7 +145,7 @@ typedef struct bpltv_stats {
     int adjoint_chunks;        /* image groups the last adjoint gradient was processed in (1 = whole batch at once;
                                   more when the factor workspace of all images does not fit, option "adjoint_budget_mb") */
     int pdhg_variant;          /* 1-based index of the PDHG kernel the last solve ran (the variant table of
-                                  csrc/bpltv.hip: 1..15 pdhg_tile_kernel, 16..18 pdhg_wave_kernel, 19.. pdhg_rows_kernel;
+                                  csrc/bpltv.hip: 1..15 pdhg_tile_kernel, 16..18 pdhg_wave_kernel, 19.. pdhg_rows_kernel and its re-cuts;
                                   sum of regularisers: 1 sr_tile_kernel, 2 sr_strip_kernel)                      */
     int ncu;                   /* compute units of the device (hipDeviceProp_t.multiProcessorCount): what bench.py prices
                                   the VALU issue floor against                                                   */

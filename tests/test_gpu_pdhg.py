@@ -43,7 +43,7 @@ def test_every_kernel_variant_and_fusion_depth_is_bit_identical(gpu_solver_cls, 
     u0 = oracle.pdhg(f, 0.08, maxiter=97)
     s = gpu_solver_cls(M, N, O)
     s.set_data(ub, f)
-    for variant in range(1, 34):
+    for variant in range(1, 37):
         for T_ in (1, 2, 5, 8):
             for chains in (1, 2):
                 for graph in (0, 1):
@@ -235,7 +235,8 @@ def test_rows_kernel_alpha_modes_and_huber(gpu_solver_cls, oracle, amode):
     shape that is no multiple of anything, every parameter form, with and without the Huber term, several fusion depths
     and region heights, f and alpha in registers or in LDS, and the re-cut with several dual chains in flight
     (pdhg_rows2_kernel, variants 30 / 31; an odd iteration count exercises its ping-pong of x), and the streaming pipeline of
-    waves (pdhg_stream_kernel, variants 32 / 33: one wave per fused iteration, LDS rings, no workgroup barrier): bit-exact
+    waves (pdhg_stream_kernel, variants 32 / 33: one wave per fused iteration, LDS rings, no workgroup barrier), and the rows of
+    128 pixels (pdhg_rowsw_kernel, variants 34 / 35 / 36: two waves side by side that exchange one column per step): bit-exact
     against the oracle.  Images narrower than a region
     are refused for these variants (the automatic plan then keeps the tile kernel)."""
     O, N, M = 2, 131, 203
@@ -246,7 +247,8 @@ def test_rows_kernel_alpha_modes_and_huber(gpu_solver_cls, oracle, amode):
     s.set_data(ub, f)
     for rho in (0.0, 0.3):
         u0 = oracle.pdhg(f, alpha, maxiter=53, rho=rho, nthreads=4)
-        for variant, T_ in ((19, 8), (19, 3), (20, 8), (21, 8), (21, 11), (24, 8), (24, 5), (29, 8), (30, 8), (30, 5), (31, 8), (31, 3), (32, 8), (32, 5), (33, 8), (33, 3)):
+        for variant, T_ in ((19, 8), (19, 3), (20, 8), (21, 8), (21, 11), (24, 8), (24, 5), (29, 8), (30, 8), (30, 5), (31, 8), (31, 3), (32, 8), (32, 5), (33, 8), (33, 3),
+                            (34, 8), (34, 3), (35, 8), (35, 5), (36, 8), (36, 11)):
             u = s.denoise(alpha, maxiter=53, rho=rho, variant=variant, tile_iters=T_)
             assert np.array_equal(u, u0), (amode, rho, variant, T_)
     s.close()
