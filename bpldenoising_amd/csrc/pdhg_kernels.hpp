@@ -466,6 +466,21 @@ __device__ __forceinline__ double pd_lane_next_or_self(double v) {
     return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false),
                             __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false));
 }
+// the same shifts with the vacated lane (0 resp. 63) taking `fill` instead (pdhg_rowsw_kernel: the neighbour wave's edge)
+__device__ __forceinline__ double pd_lane_prev_or(double v, double fill) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double pd_lane_next_or(double v, double fill) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_lane_prev_or(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_lane_next_or(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float pd_lane_prev_or0(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
@@ -759,8 +774,8 @@ __global__ __launch_bounds__(128 * TJ) void pdhg_rowsw_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj) {
             xb[pj] = T(0);
             if (it < lim[pj]) {
-                T y1m = pd_lane_prev_or0(y1[pj]);                      // lane 0 of the left wave: the zero guard column
-                if (hh) { const T e_ = sE1[tj * PJ + pj]; if (l64 == 0) y1m = e_; }   // ... of the right wave: lane 63 of the left one
+                // lane 0 of the left wave: the zero guard column; of the right wave: lane 63 of the left one (the shift's fill value)
+                const T y1m = pd_lane_prev_or(y1[pj], hh ? sE1[tj * PJ + pj] : T(0));
                 const T y2m = (pj > 0) ? y2[pj > 0 ? pj - 1 : 0] : y2up;
                 const T div = (y1m - y1[pj]) + (y2m - y2[pj]);
                 const T tt = div - (CL ? sfc[(lj0 + pj) * 128 + ti] : f[pj]);
@@ -782,8 +797,8 @@ __global__ __launch_bounds__(128 * TJ) void pdhg_rowsw_kernel(PdhgArgs A) {
         for (int pj = 0; pj < PJ; ++pj) {
             if (it < lim[pj]) {
                 const T b = xb[pj];
-                T xp1 = pd_lane_next_or_self(b);                       // lane 63 of the right wave: own value
-                if (!hh) { const T e_ = sEx[tj * PJ + pj]; if (l64 == 63) xp1 = e_; }   // ... of the left wave: lane 0 of the right one
+                // lane 63 of the right wave: own value; of the left wave: lane 0 of the right one
+                const T xp1 = pd_lane_next_or(b, hh ? b : sEx[tj * PJ + pj]);
                 const T xpM = (pj < PJ - 1) ? xb[pj < PJ - 1 ? pj + 1 : pj] : (hasD_last ? xbdn : b);
                 const T d1 = xp1 - b;
                 const T d2 = xpM - b;
