@@ -10,14 +10,29 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import bench
 from bpldenoising_amd import TVSolver
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
 ub, f, _ = bench.load_batch("faces_train_128_10", 10, 128, 128, 20211004)
 s = TVSolver(128, 128, 10); s.set_data(ub, f)
 a = np.array([0.1])
 log = (C.c_longlong * (2 * 4096))()
 
 
+EVAL = "evaluate" in sys.argv      # every step a whole evaluate (PDHG + loss + adjoint gradient): the PDHG of the next one starts behind an adjoint
+_params = s.params
+
+
+def _params_dbg(*a_, **kw):
+    p = _params(*a_, **kw)
+    p.reserved[3] = 1024
+    return p
+
+
 def run(dbg):
+    if EVAL:
+        s.params = _params_dbg
+        s.evaluate(0.1, 0.1, fetch_u=False, maxiter=5000)
+        s.params = _params
+        return s.stats()
     p = s.params(maxiter=5000)
     p.reserved[3] = dbg
     s._check(s._lib.bpltv_denoise(s._h, a.ctypes.data_as(C.POINTER(C.c_double)), 1, 1, C.byref(p), None))
@@ -60,6 +75,8 @@ if slow[0] > 1.1 * fast[0]:
     describe("slow", slow)
     for r in [r for r in res if r[0] > 1.03 * fast[0]][:6]:
         describe("slow-ish", r)
+elif np.median(ms) > 1.03 * fast[0]:
+    describe("median", sorted(res, key=lambda r: r[0])[len(res) // 2])
     sl = [r for r in res if r[0] > 1.1 * fast[0]]
     print("start offsets (chain 1 - chain 0, us) of the slow steps: %s" % " ".join("%.1f" % (r[2][0] - r[1][0]) for r in sl))
 print("start offsets of the fast steps: %s" % " ".join("%.1f" % (r[2][0] - r[1][0]) for r in res if r[0] <= 1.1 * fast[0]))
